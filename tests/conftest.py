@@ -1,0 +1,42 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, "tests", "golden")
+GEOMS = {"G256": (128, 256), "G128": (64, 128)}  # name -> (template_size, search_size)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def golden_files(prefix="ref_G"):
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+
+
+def load_case(path):
+    """Return (fixture dict, state dict, z, x) for one golden file; weights and inputs are
+    regenerated from the seed and checked against the checksum stored at generation time."""
+    from vittracker_amd import synth
+    g = dict(np.load(path, allow_pickle=False))
+    geom, seed, B = str(g["geom"]), int(g["seed"]), int(g["B"])
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(seed, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    assert synth.state_checksum(sd) == str(g["state_checksum"]), \
+        "vittracker_amd/synth.py drifted from the generator the fixtures were made with"
+    z, x = synth.synth_inputs(seed, B, tz, tx)
+    return g, sd, z, x
+
+
+@pytest.fixture(scope="session")
+def native():
+    """The C-ABI library (loads everywhere; compute calls need a GPU)."""
+    from vittracker_amd import native as nat
+    return nat

@@ -1,0 +1,79 @@
+"""Pin the CPU oracles against the reference's own outputs (tests/golden/*.npz).
+
+The fixtures were produced by running the reference model code itself
+(tests/golden/make_golden.py); these tests are what makes the oracle trustworthy before it is
+used to judge the HIP kernels.  Tolerances: the oracle and the reference both compute in fp32
+but in different summation orders, so maps agree to ~1e-5 absolute; bboxes must be identical up
+to that noise because every fixture's argmax margin is >= 1e-3.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_case
+from oracle import vt_oracle_np as onp
+
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_numpy_oracle_matches_reference(path):
+    g, sd, z, x = load_case(path)
+    out = onp.forward(sd, z, x, want_acts=True)
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+        np.testing.assert_allclose(out[k], g[k], atol=TOL, rtol=0, err_msg=k)
+    assert onp.top2_margin(g["score_map"]).min() > 5e-4  # fixtures must stay far from argmax flips
+    np.testing.assert_allclose(onp.hann2d(g["score_map"].shape[-1]), g["hann_window"], atol=1e-7)
+    # per-stage activations where the fixture carries them
+    a = out["acts"]
+    if "act_norm" in g:
+        for i in range(4):
+            np.testing.assert_allclose(a["stem_z"][i], g[f"act_stem{i}_z"], atol=TOL, err_msg=f"stem{i}_z")
+            np.testing.assert_allclose(a["stem_x"][i], g[f"act_stem{i}_x"], atol=TOL, err_msg=f"stem{i}_x")
+        for i in range(3):
+            np.testing.assert_allclose(a[f"block{i}"], g[f"act_block{i}"], atol=TOL, err_msg=f"block{i}")
+        np.testing.assert_allclose(a["norm"], g["act_norm"], atol=TOL)
+        for t in ("ctr", "offset", "size"):
+            for i in range(4):
+                np.testing.assert_allclose(a[f"head_{t}"][i], g[f"act_head_{t}{i + 1}"], atol=TOL,
+                                           err_msg=f"head_{t}{i + 1}")
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_fp64_truth_brackets_reference(path):
+    """The float64 run of the oracle is the yardstick: the reference's fp32 output sits within
+    ~1e-5 of it, which is the noise floor any fp32 implementation (ours included) shares."""
+    g, sd, z, x = load_case(path)
+    out = onp.forward(sd, z, x, dtype=np.float64)
+    for k in ("score_map", "size_map", "offset_map"):
+        assert np.abs(out[k] - g[k]).max() < TOL, k
+
+
+@pytest.mark.parametrize("path", golden_files()[:3], ids=lambda p: p.split("/")[-1][:-4])
+def test_torch_oracle_matches_reference(path):
+    import torch
+    from oracle import vt_oracle_torch as ot
+    g, sd, z, x = load_case(path)
+    m = ot.build_from_state(sd)
+    with torch.no_grad():
+        out = m(torch.from_numpy(z), torch.from_numpy(x))
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
+
+
+def test_clip_box_and_hann_known_answers():
+    import os
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "ref_clip_box.npz"))
+    for b, c in zip(g["boxes"].tolist(), g["clipped"].tolist()):
+        assert onp.clip_box(b, int(g["H"]), int(g["W"]), int(g["margin"])) == pytest.approx(c, abs=0)
+    h = np.load(os.path.join(GOLDEN_DIR, "ref_hann.npz"))
+    for n in (8, 16, 20):
+        np.testing.assert_allclose(onp.hann2d(n), h[f"hann{n}"], atol=1e-7)
+
+
+def test_mac_counts_match_survey():
+    """hook-counted MACs of the reference model."""
+    g256 = onp.macs_per_frame(128, 256)
+    assert (g256["stem"], g256["blocks"], g256["head"], g256["total"]) == (13271040, 56033280, 15266816, 84571136)
+    g128 = onp.macs_per_frame(64, 128)
+    assert (g128["stem"], g128["blocks"], g128["head"], g128["total"]) == (3317760, 8478720, 3816704, 15613184)

@@ -1,0 +1,101 @@
+"""Deterministic synthetic weights and crops for the vit_dist hot path.
+
+There is no trained checkpoint in the reference tree (``.MISSING_LARGE_BLOBS``) and no network
+here, so parity fixtures, tests and ``bench.py`` all draw weights and inputs from ONE frozen
+stream generator (``numpy.random.RandomState(seed)``, draws in a fixed order, float64 then cast
+to float32).  The same function runs in ``tests/golden/make_golden.py`` (which feeds the
+reference model) and in the tests (which feed the oracle and the HIP path), so weights never
+need to be committed; every fixture stores ``state_checksum`` to detect drift of this file.
+
+Key names and shapes are the reference's ``ckpt['net']`` layout (SURVEY.md Appendix A;
+``lib/models/vit_dist/vit_dist.py:10-75``, ``lib/models/layers/head.py:8-21,99-128``).
+Scales are chosen so activations stay O(1) through the net, attention logits have unit-ish
+spread (so softmax is neither flat nor one-hot) and BatchNorm running stats are non-trivial.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+STEM_CH = lambda C: [3, C // 8, C // 4, C // 2, C]  # noqa: E731  (b16(): vit_dist.py:36-44)
+
+
+def head_channels(C: int, W: int):
+    """(cin, cout) of the four 3x3 head convs (lib/models/layers/head.py:106-109)."""
+    return [(C, W), (W, W // 2), (W // 2, W // 4), (W // 4, W // 8)]
+
+
+def synth_state_dict(seed: int = 0, C: int = 48, depth: int = 3, head_ch: int = 32,
+                     len_z: int = 64, len_x: int = 256, mlp_ratio: int = 4) -> dict:
+    rs = np.random.RandomState(seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rs.standard_normal(shape) * std).astype(np.float32)
+
+    def uniform(shape, lo, hi):
+        return rs.uniform(lo, hi, shape).astype(np.float32)
+
+    def bn(prefix, n):
+        sd[prefix + ".weight"] = uniform((n,), 0.8, 1.2)
+        sd[prefix + ".bias"] = normal((n,), 0.1)
+        sd[prefix + ".running_mean"] = normal((n,), 0.1)
+        sd[prefix + ".running_var"] = uniform((n,), 0.5, 1.5)
+        sd[prefix + ".num_batches_tracked"] = np.array(1234, dtype=np.int64)
+
+    sd["pos_embed_z"] = normal((1, len_z, C), 0.1)
+    sd["pos_embed_x"] = normal((1, len_x, C), 0.1)
+
+    ch = STEM_CH(C)
+    for i in range(4):
+        cin, cout = ch[i], ch[i + 1]
+        sd[f"patch_embed.net.{2 * i}.c.weight"] = normal((cout, cin, 3, 3), (2.0 / (cin * 9)) ** 0.5)
+        bn(f"patch_embed.net.{2 * i}.bn", cout)
+
+    H = C * mlp_ratio
+    for b in range(depth):
+        p = f"blocks.{b}."
+        sd[p + "norm1.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+        sd[p + "norm1.bias"] = normal((C,), 0.05)
+        sd[p + "attn.qkv.weight"] = normal((3 * C, C), 1.3 / C ** 0.5)
+        sd[p + "attn.qkv.bias"] = normal((3 * C,), 0.1)
+        sd[p + "attn.proj.weight"] = normal((C, C), 0.5 / C ** 0.5)
+        sd[p + "attn.proj.bias"] = normal((C,), 0.05)
+        sd[p + "norm2.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+        sd[p + "norm2.bias"] = normal((C,), 0.05)
+        sd[p + "mlp.fc1.weight"] = normal((H, C), 1.0 / C ** 0.5)
+        sd[p + "mlp.fc1.bias"] = normal((H,), 0.1)
+        sd[p + "mlp.fc2.weight"] = normal((C, H), 0.5 / H ** 0.5)
+        sd[p + "mlp.fc2.bias"] = normal((C,), 0.05)
+    sd["norm.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+    sd["norm.bias"] = normal((C,), 0.05)
+
+    for t in ("ctr", "offset", "size"):
+        for i, (cin, cout) in enumerate(head_channels(C, head_ch)):
+            sd[f"box_head.conv{i + 1}_{t}.0.weight"] = normal((cout, cin, 3, 3), (2.0 / (cin * 9)) ** 0.5)
+            sd[f"box_head.conv{i + 1}_{t}.0.bias"] = normal((cout,), 0.1)
+            bn(f"box_head.conv{i + 1}_{t}.1", cout)
+        nout = 1 if t == "ctr" else 2
+        # a hot last layer on the centre branch gives a peaked score map (argmax margins
+        # well above fp32 noise); size/offset stay in their natural ranges
+        std = {"ctr": 0.6, "offset": 0.3, "size": 0.6}[t]
+        sd[f"box_head.conv5_{t}.weight"] = normal((nout, head_ch // 8, 1, 1), std)
+        sd[f"box_head.conv5_{t}.bias"] = normal((nout,), 0.1)
+    return sd
+
+
+def synth_inputs(seed: int, B: int, template_size: int, search_size: int):
+    """N(0,1) crops, as the reference's own profiler feeds (tracking/profile_model_cpu.py:104-105)."""
+    rs = np.random.RandomState(1_000_003 + seed)
+    z = rs.standard_normal((B, 3, template_size, template_size)).astype(np.float32)
+    x = rs.standard_normal((B, 3, search_size, search_size)).astype(np.float32)
+    return z, x
+
+
+def state_checksum(sd: dict) -> str:
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    return h.hexdigest()[:16]
