@@ -1,0 +1,128 @@
+/* vittrack.h -- C ABI of the MI355X-native vit_dist inference path (libvittrack_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of lpylpy0514/VitTracker: the per-frame forward of the
+ * `vit_dist` tracker.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only: no torch / Python
+ * types cross this boundary.  Device pointers are HIP device addresses (fp32, contiguous);
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative VT_ERR_* code; vt_last_error() gives a
+ *     human-readable message for the calling thread (the reference raises Python exceptions,
+ *     lib/test/evaluation/running.py:138-142 swallows them per sequence).
+ *   - No entry point that takes a `stream` synchronises with the host or allocates memory, so all
+ *     of them may be captured into a hipGraph (the reference syncs once per frame in `.tolist()`,
+ *     lib/test/tracker/vit_dist.py:108-109; here the caller decides when to read results back).
+ *   - One vt_model per process per GPU; a model is not thread-safe (the reference runs one
+ *     tracker instance per worker process, lib/test/evaluation/running.py:105-112).
+ */
+#ifndef VITTRACK_H
+#define VITTRACK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_OK 0
+#define VT_ERR_ARG (-1)         /* bad argument / unsupported geometry */
+#define VT_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define VT_ERR_STATE (-3)       /* weights not loaded, batch larger than max_batch, ... */
+#define VT_ERR_MISSING_KEY (-4) /* vt_load_weights: a required tensor is absent or mis-shaped */
+
+typedef struct vt_model vt_model;
+typedef struct vt_graph vt_graph;
+
+/* Replaces the cfg fields read by build_ostrack_dist (lib/models/vit_dist/vit_dist.py:159-164)
+ * and build_box_head CENTER (lib/models/layers/head.py:352-359). */
+typedef struct vt_config {
+    int32_t template_size; /* DATA.TEMPLATE.SIZE  (128; 64 for G128) */
+    int32_t search_size;   /* DATA.SEARCH.SIZE    (256; 128 for G128) */
+    int32_t channels;      /* MODEL.BACKBONE.CHANNELS (48)  */
+    int32_t heads;         /* MODEL.BACKBONE.HEADS    (1)   */
+    int32_t depth;         /* build_ostrack_dist(depth=3)   */
+    int32_t head_channels; /* MODEL.HEAD.NUM_CHANNELS (32)  */
+    int32_t stride;        /* MODEL.BACKBONE.STRIDE   (16)  */
+    int32_t max_batch;     /* workspace is sized for this many frames per call */
+} vt_config;
+
+/* One named host tensor of the reference's ckpt['net'] state dict. */
+typedef struct vt_tensor {
+    const char* name;  /* e.g. "blocks.0.attn.qkv.weight" */
+    const float* data; /* host pointer, fp32, contiguous, PyTorch layout */
+    int64_t numel;
+} vt_tensor;
+
+/* Device output buffers of one forward; any pointer may be NULL (that output is then kept in
+ * the model's own scratch).  Shapes follow OstrackDist.forward_head's dict
+ * (lib/models/vit_dist/vit_dist.py:149-152) plus the tracker's Hann-windowed decode. */
+typedef struct vt_outputs {
+    float* score_map;  /* (B,1,F,F)  clamp(sigmoid)            head.py:201 */
+    float* size_map;   /* (B,2,F,F)  clamp(sigmoid)            head.py:201 */
+    float* offset_map; /* (B,2,F,F)  raw                       head.py:201 */
+    float* pred_boxes; /* (B,4) cx,cy,w,h from the raw score   head.py:136,142-160 */
+    float* hann_boxes; /* (B,4) cx,cy,w,h from hann2d*score    lib/test/tracker/vit_dist.py:104-105 */
+    float* conf;       /* (B,)  max of the raw score map       lib/test/tracker/vit_dist.py:148 */
+} vt_outputs;
+
+const char* vt_last_error(void);
+const char* vt_version(void);
+
+/* build_ostrack_dist(cfg) + .cuda() on the current device (vit_dist.py:159-164;
+ * lib/test/tracker/vit_dist.py:24-28).  Supported: channels 48, heads 1, head_channels 32,
+ * stride 16, (template,search) in {(64,128), (128,256)}. */
+int vt_create(const vt_config* cfg, vt_model** out);
+void vt_destroy(vt_model* m);
+
+/* network.load_state_dict(ckpt['net'], strict=False) (lib/test/tracker/vit_dist.py:25):
+ * unknown names (e.g. training-only convs.*) are ignored, a missing required name is an error.
+ * BatchNorm is folded into the convs here exactly as Conv2d_BN.fuse does
+ * (lib/models/vit_dist/vit_dist.py:22-33), weights are packed into MFMA operand images and
+ * uploaded. */
+int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n);
+
+/* Overrides the motion window (default: hann2d(F), lib/test/utils/hann.py:6-16, computed at
+ * vt_create).  host_window: F*F floats. */
+int vt_set_window(vt_model* m, const float* host_window);
+
+/* OstrackDist.forward(z, x) + CenterPredictor.forward + the tracker's windowed cal_bbox
+ * (vit_dist.py:77-100,122-153; head.py:130-160; lib/test/tracker/vit_dist.py:103-105).
+ * z_dev (B,3,Tz,Tz), x_dev (B,3,Tx,Tx) NCHW fp32 on the device. */
+int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void* stream,
+               const vt_outputs* out);
+
+/* --- the three stages of vt_forward, individually (parity tests, profiling) ----------------- */
+/* patch_embed(z), patch_embed(x), += pos_embed, cat (vit_dist.py:78-84) -> tokens (B,L,C). */
+int vt_stem(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void* stream,
+            float* tokens_dev);
+/* blocks[0..nblocks) then self.norm (vit_dist.py:88-94).  nblocks<0 = all.  feat_dev (B,Lx,C) =
+ * normalised search tokens (the head's input, vit_dist.py:126); resid_dev (B,L,C), optional =
+ * the un-normalised residual stream after the last executed block. */
+int vt_blocks(vt_model* m, const float* tokens_dev, int32_t B, int32_t nblocks, void* stream,
+              float* feat_dev, float* resid_dev);
+/* forward_head + CenterPredictor (vit_dist.py:122-153; head.py:130-201) on (B,Lx,C) tokens. */
+int vt_head(vt_model* m, const float* feat_dev, int32_t B, void* stream, const vt_outputs* out);
+
+/* box_head.cal_bbox(score, size, offset, return_score=True) (head.py:142-160) on arbitrary
+ * device maps: bbox_dev (B,4), max_score_dev (B,) optional. First maximum wins ties. */
+int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, const float* offset_dev,
+                int32_t B, void* stream, float* bbox_dev, float* max_score_dev);
+
+/* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
+int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,
+                     const vt_outputs* out, vt_graph** g);
+int vt_graph_launch(vt_graph* g, void* stream);
+void vt_graph_destroy(vt_graph* g);
+
+/* Geometry / workspace queries (host side of build_box_head: feat_sz etc.). */
+int vt_query(const vt_model* m, int32_t* len_z, int32_t* len_x, int32_t* feat_sz, int32_t* channels);
+
+/* MFMA lane-map self test: runs v_mfma_f32_16x16x4_f32 on exact integer data with an
+ * asymmetric B and checks the operand / result lane maps the kernels rely on. 0 = as assumed. */
+int vt_selftest_mfma(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITTRACK_H */

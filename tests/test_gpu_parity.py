@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden vectors and the
+pinned CPU oracle, stage by stage and end to end.
+
+Tolerances.  north_star asks for 1e-3 on fp32 outputs; we hold maps and activations to 1e-4
+absolute (fp32 noise of this net is ~2e-6, see tests/test_oracle_golden.py) and require bboxes to
+match to 1e-5 because every fixture's argmax margin is >= 1e-3, i.e. no flip is excusable.
+"""
+import numpy as np
+import pytest
+
+from conftest import GEOMS, golden_files, load_case
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACT = 1e-4
+TOL_MAP = 1e-4
+TOL_BOX = 1e-5
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def _model(sd, geom, max_batch):
+    from vittracker_amd import native
+    tz, tx = GEOMS[geom]
+    m = native.Model(tz, tx, max_batch=max_batch)
+    m.load_state_dict(sd)
+    return m
+
+
+def _dev(a):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_mfma_lane_map():
+    from vittracker_amd import native
+    _torch()
+    native.selftest_mfma()
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_forward_matches_reference_golden(path):
+    g, sd, z, x = load_case(path)
+    m = _model(sd, str(g["geom"]), int(g["B"]))
+    out = m.forward(_dev(z), _dev(x))
+    for k in ("score_map", "size_map", "offset_map"):
+        np.testing.assert_allclose(getattr(out, k).cpu().numpy(), g[k], atol=TOL_MAP, rtol=0, err_msg=k)
+    np.testing.assert_allclose(out.pred_boxes.cpu().numpy(), g["pred_boxes"][:, 0], atol=TOL_BOX, rtol=0)
+    np.testing.assert_allclose(out.hann_boxes.cpu().numpy(), g["hann_boxes"], atol=TOL_BOX, rtol=0)
+    np.testing.assert_allclose(out.conf.cpu().numpy(), g["conf"], atol=TOL_MAP, rtol=0)
+
+
+@pytest.mark.parametrize("path", [p for p in golden_files() if "_b1" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_each_stage_against_reference_activations(path):
+    """Feeds every stage the REFERENCE's activation of the previous stage, so an error cannot hide
+    behind (or be blamed on) an upstream one."""
+    g, sd, z, x = load_case(path)
+    geom = str(g["geom"])
+    m = _model(sd, geom, 1)
+    torch = _torch()
+    # stem -> tokens (reference: stem3 output tokenised + pos-embed, vit_dist.py:78-84)
+    def tok(a, pos):
+        B, C, H, W = a.shape
+        return a.reshape(B, C, H * W).transpose(0, 2, 1) + pos
+    ref_tokens = np.concatenate([tok(g["act_stem3_z"], sd["pos_embed_z"]), tok(g["act_stem3_x"], sd["pos_embed_x"])], 1)
+    got = m.stem(_dev(z), _dev(x)).cpu().numpy()
+    np.testing.assert_allclose(got, ref_tokens, atol=TOL_ACT, rtol=0, err_msg="stem tokens")
+    # blocks, one at a time from the reference's tokens
+    tokens = _dev(ref_tokens.astype(np.float32))
+    for nb in (1, 2, 3):
+        feat, resid = m.blocks(tokens, nblocks=nb, want_resid=True)
+        np.testing.assert_allclose(resid.cpu().numpy(), g[f"act_block{nb - 1}"], atol=TOL_ACT, rtol=0,
+                                   err_msg=f"residual after block {nb - 1}")
+    np.testing.assert_allclose(feat.cpu().numpy(), g["act_norm"][:, -m.len_x:], atol=TOL_ACT, rtol=0, err_msg="norm")
+    # head from the reference's normalised tokens
+    out = m.head(_dev(g["act_norm"][:, -m.len_x:].astype(np.float32)))
+    torch.cuda.synchronize()
+    for k in ("score_map", "size_map", "offset_map"):
+        np.testing.assert_allclose(getattr(out, k).cpu().numpy(), g[k], atol=TOL_MAP, rtol=0, err_msg="head " + k)
+
+
+def test_oracle_agrees_on_fresh_seeds_g128():
+    """Seeds with no committed fixture: HIP vs the pinned numpy oracle (maps) and, where the
+    oracle's argmax margin allows, boxes."""
+    from oracle import vt_oracle_np as onp
+    from vittracker_amd import synth
+    for seed in (11, 12):
+        sd = synth.synth_state_dict(seed, len_z=16, len_x=64)
+        z, x = synth.synth_inputs(seed, 16, 64, 128)
+        ref = onp.forward(sd, z, x)
+        m = _model(sd, "G128", 16)
+        out = m.forward(_dev(z), _dev(x))
+        for k in ("score_map", "size_map", "offset_map"):
+            np.testing.assert_allclose(getattr(out, k).cpu().numpy(), ref[k], atol=TOL_MAP, rtol=0)
+        ok = onp.top2_margin(ref["score_map"]) > 1e-3
+        np.testing.assert_allclose(out.pred_boxes.cpu().numpy()[ok], ref["pred_boxes"][ok, 0], atol=TOL_BOX)
+        win = onp.hann2d(8)
+        okh = onp.top2_margin(ref["score_map"] * win) > 1e-3
+        np.testing.assert_allclose(out.hann_boxes.cpu().numpy()[okh], ref["hann_boxes"][okh], atol=TOL_BOX)
+
+
+def test_cal_bbox_ties_take_first_index():
+    """torch.max on CPU returns the first maximum; head.py:143 relies on it implicitly."""
+    from oracle import vt_oracle_np as onp
+    from vittracker_amd import synth
+    rs = np.random.RandomState(5)
+    F = 8
+    sd = synth.synth_state_dict(0, len_z=16, len_x=64)
+    m = _model(sd, "G128", 8)
+    score = rs.uniform(0, 0.5, (8, 1, F, F)).astype(np.float32)
+    for b in range(8):            # plant exact ties at two positions, later index first in memory order
+        i, j = sorted(rs.choice(F * F, 2, replace=False))
+        score.reshape(8, -1)[b, [i, j]] = 0.75
+    size = rs.uniform(0, 1, (8, 2, F, F)).astype(np.float32)
+    off = rs.uniform(-0.5, 0.5, (8, 2, F, F)).astype(np.float32)
+    bbox, mx = m.cal_bbox(_dev(score), _dev(size), _dev(off))
+    ref, rmx, _ = onp.cal_bbox(score, size, off, F)
+    np.testing.assert_array_equal(bbox.cpu().numpy(), ref)
+    np.testing.assert_array_equal(mx.cpu().numpy(), rmx)
+
+
+def test_graph_replay_equals_eager_and_is_deterministic():
+    from vittracker_amd import synth
+    torch = _torch()
+    sd = synth.synth_state_dict(3, len_z=16, len_x=64)
+    z, x = synth.synth_inputs(3, 32, 64, 128)
+    m = _model(sd, "G128", 32)
+    zd, xd = _dev(z), _dev(x)
+    eager = m.forward(zd, xd)
+    torch.cuda.synchronize()
+    graph, gout = m.capture(zd, xd)
+    for _ in range(3):
+        graph.launch()
+    torch.cuda.synchronize()
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+        assert torch.equal(getattr(eager, k), getattr(gout, k)), k
+
+
+@pytest.mark.parametrize("geom,B", [("G128", 256), ("G256", 64)])
+def test_full_batch_is_batch_invariant(geom, B):
+    """At BASELINE.json's full batch: frame i of a big batch equals the same frame run alone
+    (frames are independent sequences; no cross-frame state), and a permuted batch permutes the
+    outputs.  Size-independent property, no oracle run needed at this size."""
+    from vittracker_amd import synth
+    torch = _torch()
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    z, x = synth.synth_inputs(9, B, tz, tx)
+    m = _model(sd, geom, B)
+    zd, xd = _dev(z), _dev(x)
+    big = m.forward(zd, xd)
+    perm = torch.randperm(B, device="cuda")
+    pm = m.forward(zd[perm].contiguous(), xd[perm].contiguous())
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+        assert torch.equal(getattr(big, k)[perm], getattr(pm, k)), k
+    for i in (0, B // 2, B - 1):
+        one = m.forward(zd[i:i + 1].contiguous(), xd[i:i + 1].contiguous())
+        assert torch.equal(one.score_map[0], big.score_map[i])
+        assert torch.equal(one.hann_boxes[0], big.hann_boxes[i])

@@ -1,0 +1,522 @@
+// vittrack.hip -- C-ABI runtime of libvittrack_hip.so (see include/vittrack.h).
+// Host side: config checks, BatchNorm folding, MFMA operand-image packing, workspace, launches,
+// hipGraph capture.  Device side: vt_stem.h / vt_blocks.h / vt_head.h.
+#include "../../include/vittrack.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vt_blocks.h"
+#include "vt_head.h"
+#include "vt_stem.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(VT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t floats) {
+        n = floats;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), floats * sizeof(float));
+        if (e != hipSuccess) return fail(VT_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        return VT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+constexpr int STEM_CH[5] = {3, 6, 12, 24, 48};
+constexpr int STEM_OCG[4] = {6, 12, 12, 12};   // output channels per thread, per layer
+
+}  // namespace
+
+struct vt_model {
+    vt_config cfg{};
+    int len_z = 0, len_x = 0, L = 0, F = 0, Fz = 0;
+    bool weights_loaded = false;
+    // parameters on the device
+    DevBuf stem_w[4], stem_b[4];     // folded, [group][tap][cin][OCG] / [cout]
+    DevBuf pos_z, pos_x;             // (len, C)
+    DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
+    DevBuf head;                     // 3 * TOWER_STRIDE
+    DevBuf window;                   // F*F
+    // workspace sized for max_batch
+    DevBuf act_x[3], act_z[3];       // NHWC stem intermediates
+    DevBuf tokens, feat;
+    DevBuf score, size, offset, pred, hann, conf;
+    hipStream_t cap_stream = nullptr;
+};
+
+struct vt_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------- weight packing
+using TensorMap = std::map<std::string, std::pair<const float*, int64_t>>;
+
+int need(const TensorMap& tm, const std::string& name, int64_t numel, const float** out) {
+    auto it = tm.find(name);
+    if (it == tm.end()) return fail(VT_ERR_MISSING_KEY, "missing key in state dict: " + name);
+    if (it->second.second != numel)
+        return fail(VT_ERR_MISSING_KEY, "shape mismatch for " + name + ": got " + std::to_string(it->second.second) +
+                                            " elements, want " + std::to_string(numel));
+    *out = it->second.first;
+    return VT_OK;
+}
+
+// BN(eval) folded into the preceding conv, in double:  w' = w * g / sqrt(var + eps),
+// b' = (b_conv - mean) * g / sqrt(var + eps) + beta      (Conv2d_BN.fuse, vit_dist.py:22-33)
+int fold_conv_bn(const TensorMap& tm, const std::string& conv, const std::string& bn, bool conv_bias, int cout,
+                 int cin, std::vector<double>& w, std::vector<double>& b) {
+    const float *pw, *pb = nullptr, *g, *beta, *mu, *var;
+    int rc;
+    if ((rc = need(tm, conv + ".weight", (int64_t)cout * cin * 9, &pw))) return rc;
+    if (conv_bias && (rc = need(tm, conv + ".bias", cout, &pb))) return rc;
+    if ((rc = need(tm, bn + ".weight", cout, &g))) return rc;
+    if ((rc = need(tm, bn + ".bias", cout, &beta))) return rc;
+    if ((rc = need(tm, bn + ".running_mean", cout, &mu))) return rc;
+    if ((rc = need(tm, bn + ".running_var", cout, &var))) return rc;
+    w.resize((size_t)cout * cin * 9);
+    b.resize(cout);
+    for (int o = 0; o < cout; ++o) {
+        const double k = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+        for (int i = 0; i < cin * 9; ++i) w[(size_t)o * cin * 9 + i] = (double)pw[(size_t)o * cin * 9 + i] * k;
+        b[o] = ((conv_bias ? (double)pb[o] : 0.0) - (double)mu[o]) * k + (double)beta[o];
+    }
+    return VT_OK;
+}
+
+// [cout][cin][3][3] -> [group][tap][cin][ocg]
+std::vector<float> pack_conv_groups(const std::vector<double>& w, int cout, int cin, int ocg) {
+    std::vector<float> out((size_t)cout * cin * 9);
+    const int ng = cout / ocg;
+    for (int g = 0; g < ng; ++g)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < cin; ++c)
+                for (int j = 0; j < ocg; ++j)
+                    out[(((size_t)g * 9 + tap) * cin + c) * ocg + j] = (float)w[((size_t)(g * ocg + j) * cin + c) * 9 + tap];
+    return out;
+}
+
+// nn.Linear weight (OUT, IN) -> MFMA operand images [OUT/16][IN/16][64 lanes][4]:
+// element r of lane l of tile (ot, c) = W[16 ot + (l & 15)][16 c + 4 (l >> 4) + r]   (vt_common.h)
+void pack_linear_image(const float* W, int OUT, int IN, float* dst) {
+    const int nc = IN / 16;
+    for (int ot = 0; ot < OUT / 16; ++ot)
+        for (int c = 0; c < nc; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r)
+                    dst[(((size_t)ot * nc + c) * 64 + l) * 4 + r] = W[(size_t)(16 * ot + (l & 15)) * IN + 16 * c + 4 * (l >> 4) + r];
+}
+
+int upload(DevBuf& d, const std::vector<float>& h) {
+    if (!d.p || d.n != h.size()) {
+        d.release();
+        int rc = d.alloc(h.size());
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpy(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return VT_OK;
+}
+
+// lib/test/utils/hann.py:6-16, float32 like torch
+std::vector<float> hann2d(int F) {
+    std::vector<float> w1(F), w((size_t)F * F);
+    const float k = (float)(2.0 * M_PI / (F + 1));
+    for (int i = 0; i < F; ++i) w1[i] = 0.5f * (1.0f - cosf(k * (float)(i + 1)));
+    for (int y = 0; y < F; ++y)
+        for (int x = 0; x < F; ++x) w[(size_t)y * F + x] = w1[y] * w1[x];
+    return w;
+}
+
+// ------------------------------------------------------------------------------------- launches
+template <int CIN, int COUT, int OCG, bool NCHW, bool HSW, bool TOK>
+void launch_conv(hipStream_t st, const float* in, const float* w, const float* b, float* out, int B, int H, int W,
+                 const float* pos, int tok_off, int L) {
+    const int npix = B * (H / 2) * (W / 2);
+    dim3 grid((npix + 255) / 256, COUT / OCG);
+    hipLaunchKernelGGL((vts::conv_s2_kernel<CIN, COUT, OCG, NCHW, HSW, TOK>), grid, dim3(256), 0, st, in, w, b, out, B,
+                       H, W, pos, tok_off, L);
+}
+
+int stem_one(vt_model* m, hipStream_t st, const float* img, int T, DevBuf* act, const float* pos, int tok_off, int B,
+             float* tokens) {
+    launch_conv<3, 6, 6, true, true, false>(st, img, m->stem_w[0].p, m->stem_b[0].p, act[0].p, B, T, T, nullptr, 0, 0);
+    launch_conv<6, 12, 12, false, true, false>(st, act[0].p, m->stem_w[1].p, m->stem_b[1].p, act[1].p, B, T / 2, T / 2,
+                                               nullptr, 0, 0);
+    launch_conv<12, 24, 12, false, true, false>(st, act[1].p, m->stem_w[2].p, m->stem_b[2].p, act[2].p, B, T / 4, T / 4,
+                                                nullptr, 0, 0);
+    launch_conv<24, 48, 12, false, false, true>(st, act[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, B, T / 8, T / 8,
+                                                pos, tok_off, m->L);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int check_ready(vt_model* m, int B) {
+    if (!m) return fail(VT_ERR_ARG, "null model");
+    if (!m->weights_loaded) return fail(VT_ERR_STATE, "vt_load_weights has not been called");
+    if (B < 1 || B > m->cfg.max_batch)
+        return fail(VT_ERR_STATE, "batch " + std::to_string(B) + " outside [1, max_batch=" + std::to_string(m->cfg.max_batch) + "]");
+    return VT_OK;
+}
+
+int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens) {
+    int rc;
+    if ((rc = stem_one(m, st, z, m->cfg.template_size, m->act_z, m->pos_z.p, 0, B, tokens))) return rc;
+    return stem_one(m, st, x, m->cfg.search_size, m->act_x, m->pos_x.p, m->len_z, B, tokens);
+}
+
+template <int NT, int NW, int TPW>
+int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
+    const size_t lds = (size_t)2 * NT * vtb::NC * 64 * sizeof(f4);
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+                       resid, m->len_z, m->cfg.depth, nblocks);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid) {
+    if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
+    switch (m->L / 16) {
+        case 5: return launch_blocks<5, 5, 1>(m, st, tokens, B, nblocks, feat, resid);
+        case 20: return launch_blocks<20, 4, 5>(m, st, tokens, B, nblocks, feat, resid);
+        default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
+    }
+}
+
+int run_decode(vt_model* m, hipStream_t st, const float* score, const float* size, const float* offset,
+               const float* window, int B, float* pred, float* hann, float* conf) {
+    hipLaunchKernelGGL(vth::decode_kernel, dim3(B), dim3(64), 0, st, score, size, offset, window, m->F, pred, hann, conf);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o) {
+    float* score = (o && o->score_map) ? o->score_map : m->score.p;
+    float* size = (o && o->size_map) ? o->size_map : m->size.p;
+    float* offset = (o && o->offset_map) ? o->offset_map : m->offset.p;
+    float* pred = (o && o->pred_boxes) ? o->pred_boxes : m->pred.p;
+    float* hann = (o && o->hann_boxes) ? o->hann_boxes : m->hann.p;
+    float* conf = (o && o->conf) ? o->conf : m->conf.p;
+    if (m->F == 8) {
+        hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::HeadLds<8>::FLOATS * sizeof(float), st,
+                           feat, m->head.p, score, size, offset);
+    } else if (m->F == 16) {
+        hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::HeadLds<16>::FLOATS * sizeof(float),
+                           st, feat, m->head.p, score, size, offset);
+    } else {
+        return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
+    }
+    HIP_TRY(hipGetLastError());
+    return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
+}
+
+// ------------------------------------------------------------------------------------ self test
+__global__ void mfma_selftest_kernel(const float* A, const float* Bm, float* D) {
+    // A (16x16 k-chunk as operand image source: A[i][k]), B[k][j]; D[i][j] = sum_k A[i][k] B[k][j]
+    const int lane = threadIdx.x, rc = lane & 15, q = lane >> 4;
+    f4 a, b;
+    for (int r = 0; r < 4; ++r) {
+        a[r] = A[rc * 16 + 4 * q + r];
+        b[r] = Bm[(4 * q + r) * 16 + rc];
+    }
+    f4 acc = mfma4(a, b, splat4(0.f));
+    for (int r = 0; r < 4; ++r) D[(4 * q + r) * 16 + rc] = acc[r];
+}
+
+}  // namespace
+
+// =========================================================================================== ABI
+extern "C" {
+
+const char* vt_last_error(void) { return g_err.c_str(); }
+const char* vt_version(void) { return "vittrack-hip 0.1 (gfx950)"; }
+
+int vt_create(const vt_config* cfg, vt_model** out) {
+    if (!cfg || !out) return fail(VT_ERR_ARG, "null argument");
+    if (cfg->channels != 48 || cfg->heads != 1 || cfg->head_channels != 32 || cfg->stride != 16)
+        return fail(VT_ERR_ARG,
+                    "unsupported model: this build implements CHANNELS=48, HEADS=1, HEAD.NUM_CHANNELS=32, STRIDE=16 "
+                    "(the shipped vit_48_h32 config); got channels=" + std::to_string(cfg->channels) + " heads=" +
+                        std::to_string(cfg->heads) + " head_channels=" + std::to_string(cfg->head_channels));
+    const bool g128 = cfg->template_size == 64 && cfg->search_size == 128;
+    const bool g256 = cfg->template_size == 128 && cfg->search_size == 256;
+    if (!g128 && !g256)
+        return fail(VT_ERR_ARG, "unsupported geometry (template,search)=(" + std::to_string(cfg->template_size) + "," +
+                                    std::to_string(cfg->search_size) + "); supported: (64,128), (128,256)");
+    if (cfg->depth < 1 || cfg->depth > 12 || cfg->max_batch < 1) return fail(VT_ERR_ARG, "bad depth / max_batch");
+
+    vt_model* m = new vt_model();
+    m->cfg = *cfg;
+    m->F = cfg->search_size / 16;
+    m->Fz = cfg->template_size / 16;
+    m->len_x = m->F * m->F;
+    m->len_z = m->Fz * m->Fz;
+    m->L = m->len_x + m->len_z;
+    const size_t B = (size_t)cfg->max_batch;
+    int rc = VT_OK;
+    auto A = [&](DevBuf& d, size_t n) { if (!rc) rc = d.alloc(n); };
+    for (int i = 0; i < 3; ++i) {
+        const size_t sx = (size_t)(cfg->search_size >> (i + 1)), sz = (size_t)(cfg->template_size >> (i + 1));
+        A(m->act_x[i], B * sx * sx * STEM_CH[i + 1]);
+        A(m->act_z[i], B * sz * sz * STEM_CH[i + 1]);
+    }
+    A(m->tokens, B * m->L * 48);
+    A(m->feat, B * m->len_x * 48);
+    A(m->score, B * m->len_x);
+    A(m->size, B * 2 * m->len_x);
+    A(m->offset, B * 2 * m->len_x);
+    A(m->pred, B * 4);
+    A(m->hann, B * 4);
+    A(m->conf, B);
+    if (!rc) rc = upload(m->window, hann2d(m->F));
+    if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
+        rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
+    if (!rc) {
+        // > 64 KiB of dynamic LDS needs an explicit opt-in
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(vth::HeadLds<16>::FLOATS * sizeof(float)));
+        if (e != hipSuccess) rc = fail(VT_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    if (rc) {
+        vt_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return VT_OK;
+}
+
+void vt_destroy(vt_model* m) {
+    if (!m) return;
+    for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
+    for (int i = 0; i < 3; ++i) { m->act_x[i].release(); m->act_z[i].release(); }
+    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat,
+                     &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
+    for (DevBuf* d : all) d->release();
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    delete m;
+}
+
+int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
+    if (!m || !tensors || n < 0) return fail(VT_ERR_ARG, "null argument");
+    TensorMap tm;
+    for (int i = 0; i < n; ++i)
+        if (tensors[i].name && tensors[i].data) tm[tensors[i].name] = {tensors[i].data, tensors[i].numel};
+    int rc;
+    const int C = 48;
+    // ---- stem (patch_embed.net.{0,2,4,6}.{c,bn})
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "patch_embed.net." + std::to_string(2 * i);
+        std::vector<double> w, b;
+        if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
+        if ((rc = upload(m->stem_w[i], pack_conv_groups(w, STEM_CH[i + 1], STEM_CH[i], STEM_OCG[i])))) return rc;
+        if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+    }
+    const float* p;
+    if ((rc = need(tm, "pos_embed_z", (int64_t)m->len_z * C, &p))) return rc;
+    if ((rc = upload(m->pos_z, std::vector<float>(p, p + (size_t)m->len_z * C)))) return rc;
+    if ((rc = need(tm, "pos_embed_x", (int64_t)m->len_x * C, &p))) return rc;
+    if ((rc = upload(m->pos_x, std::vector<float>(p, p + (size_t)m->len_x * C)))) return rc;
+    // ---- transformer blocks + final norm
+    std::vector<float> bp((size_t)m->cfg.depth * vtb::BLOCK_STRIDE + 2 * C);
+    for (int b = 0; b < m->cfg.depth; ++b) {
+        const std::string pre = "blocks." + std::to_string(b) + ".";
+        float* dst = bp.data() + (size_t)b * vtb::BLOCK_STRIDE;
+        struct V { const char* name; int off; int n; };
+        const V vecs[] = {{"norm1.weight", vtb::O_LN1G, C}, {"norm1.bias", vtb::O_LN1B, C},
+                          {"attn.qkv.bias", vtb::O_BQKV, 3 * C}, {"attn.proj.bias", vtb::O_BPROJ, C},
+                          {"norm2.weight", vtb::O_LN2G, C}, {"norm2.bias", vtb::O_LN2B, C},
+                          {"mlp.fc1.bias", vtb::O_B1, 4 * C}, {"mlp.fc2.bias", vtb::O_B2, C}};
+        for (const V& v : vecs) {
+            if ((rc = need(tm, pre + v.name, v.n, &p))) return rc;
+            std::memcpy(dst + v.off, p, v.n * sizeof(float));
+        }
+        if ((rc = need(tm, pre + "attn.qkv.weight", 3 * C * C, &p))) return rc;
+        pack_linear_image(p, 3 * C, C, dst + vtb::O_WQKV);
+        if ((rc = need(tm, pre + "attn.proj.weight", C * C, &p))) return rc;
+        pack_linear_image(p, C, C, dst + vtb::O_WPROJ);
+        if ((rc = need(tm, pre + "mlp.fc1.weight", 4 * C * C, &p))) return rc;
+        pack_linear_image(p, 4 * C, C, dst + vtb::O_W1);
+        if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
+        pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
+    }
+    {
+        float* dst = bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;
+        if ((rc = need(tm, "norm.weight", C, &p))) return rc;
+        std::memcpy(dst, p, C * sizeof(float));
+        if ((rc = need(tm, "norm.bias", C, &p))) return rc;
+        std::memcpy(dst + C, p, C * sizeof(float));
+    }
+    if ((rc = upload(m->blocks, bp))) return rc;
+    // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
+    std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
+    const char* towers[3] = {"ctr", "offset", "size"};
+    const int chans[5] = {48, 32, 16, 8, 4};
+    const int woff[4] = {vth::O_W1, vth::O_W2, vth::O_W3, vth::O_W4};
+    const int boff[4] = {vth::O_B1, vth::O_B2, vth::O_B3, vth::O_B4};
+    for (int t = 0; t < 3; ++t) {
+        float* dst = hp.data() + (size_t)t * vth::TOWER_STRIDE;
+        for (int i = 0; i < 4; ++i) {
+            const std::string cn = std::string("box_head.conv") + std::to_string(i + 1) + "_" + towers[t];
+            std::vector<double> w, b;
+            if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, chans[i + 1], chans[i], w, b))) return rc;
+            std::vector<float> pk = pack_conv_groups(w, chans[i + 1], chans[i], chans[i + 1] / 4);
+            std::memcpy(dst + woff[i], pk.data(), pk.size() * sizeof(float));
+            for (int o = 0; o < chans[i + 1]; ++o) dst[boff[i] + o] = (float)b[o];
+        }
+        const int nout = t == 0 ? 1 : 2;
+        const std::string c5 = std::string("box_head.conv5_") + towers[t];
+        if ((rc = need(tm, c5 + ".weight", nout * 4, &p))) return rc;
+        std::memcpy(dst + vth::O_W5, p, nout * 4 * sizeof(float));
+        if ((rc = need(tm, c5 + ".bias", nout, &p))) return rc;
+        std::memcpy(dst + vth::O_B5, p, nout * sizeof(float));
+    }
+    if ((rc = upload(m->head, hp))) return rc;
+    m->weights_loaded = true;
+    return VT_OK;
+}
+
+int vt_set_window(vt_model* m, const float* host_window) {
+    if (!m || !host_window) return fail(VT_ERR_ARG, "null argument");
+    return upload(m->window, std::vector<float>(host_window, host_window + (size_t)m->F * m->F));
+}
+
+int vt_query(const vt_model* m, int32_t* len_z, int32_t* len_x, int32_t* feat_sz, int32_t* channels) {
+    if (!m) return fail(VT_ERR_ARG, "null model");
+    if (len_z) *len_z = m->len_z;
+    if (len_x) *len_x = m->len_x;
+    if (feat_sz) *feat_sz = m->F;
+    if (channels) *channels = m->cfg.channels;
+    return VT_OK;
+}
+
+int vt_stem(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void* stream, float* tokens_dev) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!z_dev || !x_dev || !tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
+    return run_stem(m, z_dev, x_dev, B, static_cast<hipStream_t>(stream), tokens_dev);
+}
+
+int vt_blocks(vt_model* m, const float* tokens_dev, int32_t B, int32_t nblocks, void* stream, float* feat_dev,
+              float* resid_dev) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
+    return run_blocks(m, tokens_dev, B, nblocks, static_cast<hipStream_t>(stream), feat_dev ? feat_dev : m->feat.p,
+                      resid_dev);
+}
+
+int vt_head(vt_model* m, const float* feat_dev, int32_t B, void* stream, const vt_outputs* out) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!feat_dev) return fail(VT_ERR_ARG, "null device pointer");
+    return run_head(m, feat_dev, B, static_cast<hipStream_t>(stream), out);
+}
+
+int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void* stream, const vt_outputs* out) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!z_dev || !x_dev) return fail(VT_ERR_ARG, "null device pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = run_stem(m, z_dev, x_dev, B, st, m->tokens.p))) return rc;
+    if ((rc = run_blocks(m, m->tokens.p, B, -1, st, m->feat.p, nullptr))) return rc;
+    return run_head(m, m->feat.p, B, st, out);
+}
+
+int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, const float* offset_dev, int32_t B,
+                void* stream, float* bbox_dev, float* max_score_dev) {
+    if (!m || !score_dev || !size_dev || !offset_dev || !bbox_dev || B < 1) return fail(VT_ERR_ARG, "bad argument");
+    return run_decode(m, static_cast<hipStream_t>(stream), score_dev, size_dev, offset_dev, nullptr, B, bbox_dev, nullptr,
+                      max_score_dev);
+}
+
+int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, const vt_outputs* out,
+                     vt_graph** g) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!g) return fail(VT_ERR_ARG, "null graph out");
+    vt_graph* vg = new vt_graph();
+    hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
+    rc = vt_forward(m, z_dev, x_dev, B, m->cap_stream, out);
+    e = hipStreamEndCapture(m->cap_stream, &vg->graph);
+    if (rc) { if (vg->graph) (void)hipGraphDestroy(vg->graph); delete vg; return rc; }
+    if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&vg->exec, vg->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(vg->graph); delete vg; return fail(VT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    *g = vg;
+    return VT_OK;
+}
+
+int vt_graph_launch(vt_graph* g, void* stream) {
+    if (!g || !g->exec) return fail(VT_ERR_ARG, "null graph");
+    HIP_TRY(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    return VT_OK;
+}
+
+void vt_graph_destroy(vt_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+int vt_selftest_mfma(void* stream) {
+    // exact small integers; B is asymmetric so a transposed read or write cannot pass
+    std::vector<float> A(256), Bm(256), D(256, -1.f), ref(256, 0.f);
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 16; ++k) {
+            A[i * 16 + k] = (float)((i * 3 + k * 5) % 7 - 3);
+            Bm[i * 16 + k] = (float)((i * 11 + k * 2) % 9 - 4);   // B[k=i][j=k]
+        }
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j)
+            for (int k = 0; k < 16; ++k) ref[i * 16 + j] += A[i * 16 + k] * Bm[k * 16 + j];
+    float *dA = nullptr, *dB = nullptr, *dD = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dA), 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dB), 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dD), 1024));
+    HIP_TRY(hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB, Bm.data(), 1024, hipMemcpyHostToDevice));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, st, dA, dB, dD);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+    int bad = 0;
+    for (int i = 0; i < 256; ++i) bad += (D[i] != ref[i]);
+    if (bad) return fail(VT_ERR_STATE, "MFMA lane map differs from the assumed one in " + std::to_string(bad) + " / 256 elements");
+    return VT_OK;
+}
+
+}  // extern "C"

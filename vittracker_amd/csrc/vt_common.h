@@ -1,0 +1,55 @@
+// vt_common.h -- shared device helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define VT_WAVE 64
+
+// Four chained v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains, 16 k-values per call).
+// Operand convention used everywhere ("operand image"): a lane's f4 holds, for its row/column
+// index (lane & 15) and quarter q = lane >> 4, the four k-values 4q + r (r = 0..3) of a 16-wide
+// k chunk.  MFMA step r consumes element r of both operands, so step r's hardware k-slot
+// (lane >> 4) stands for k = 4q + r on BOTH sides: the k order is permuted identically for A and
+// B, which leaves the product unchanged.  Result: D[row = 4q + r][col = lane & 15] in element r.
+__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ f4 splat4(float v) { return f4{v, v, v, v}; }
+
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// Sum / max over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float hmax4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
+
+__device__ __forceinline__ float gelu_erf(float u) {
+    // nn.GELU() exact form: 0.5 u (1 + erf(u / sqrt 2))
+    return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float hardswish(float y) {
+    return y * fminf(fmaxf(y + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
+}
+__device__ __forceinline__ float sigmoid_clamped(float v) {
+    // torch.clamp(x.sigmoid_(), 1e-4, 1 - 1e-4)   (lib/models/layers/head.py:177-179)
+    float y = 1.0f / (1.0f + expf(-v));
+    return fminf(fmaxf(y, 1e-4f), 1.0f - 1e-4f);
+}

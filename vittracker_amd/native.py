@@ -1,0 +1,224 @@
+"""ctypes binding of ``libvittrack_hip.so`` (C ABI declared in ``include/vittrack.h``).
+
+PyTorch is plumbing here: it owns device memory and streams; every kernel launch goes through
+the C ABI with raw device pointers.  There is NO fallback: if the library is missing or a call
+fails, an exception is raised (``VtError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvittrack_hip.so")
+
+#: every symbol include/vittrack.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
+    "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
+    "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma",
+]
+
+
+class VtError(RuntimeError):
+    pass
+
+
+class VtConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("template_size", "search_size", "channels", "heads", "depth",
+                                         "head_channels", "stride", "max_batch")]
+
+
+class VtTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("numel", C.c_int64)]
+
+
+class VtOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")]
+
+
+_lib = None
+
+
+def lib():
+    """Load the library once.  Raises VtError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C vittracker_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.vt_last_error.restype = C.c_char_p
+    L.vt_version.restype = C.c_char_p
+    L.vt_create.argtypes = [C.POINTER(VtConfig), C.POINTER(vp)]
+    L.vt_destroy.argtypes = [vp]
+    L.vt_destroy.restype = None
+    L.vt_load_weights.argtypes = [vp, C.POINTER(VtTensor), i32]
+    L.vt_set_window.argtypes = [vp, vp]
+    L.vt_forward.argtypes = [vp, vp, vp, i32, vp, C.POINTER(VtOutputs)]
+    L.vt_stem.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.vt_blocks.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.vt_head.argtypes = [vp, vp, i32, vp, C.POINTER(VtOutputs)]
+    L.vt_cal_bbox.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    L.vt_graph_capture.argtypes = [vp, vp, vp, i32, C.POINTER(VtOutputs), C.POINTER(vp)]
+    L.vt_graph_launch.argtypes = [vp, vp]
+    L.vt_graph_destroy.argtypes = [vp]
+    L.vt_graph_destroy.restype = None
+    L.vt_query.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.vt_selftest_mfma.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise VtError(f"{what} failed ({rc}): {lib().vt_last_error().decode()}")
+
+
+def _ptr(t):
+    """Device pointer of a contiguous fp32 CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise VtError("expected a contiguous float32 tensor on the GPU, got "
+                      f"{type(t).__name__} {getattr(t, 'dtype', '')} {getattr(t, 'device', '')}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def selftest_mfma():
+    _check(lib().vt_selftest_mfma(_stream(None)), "vt_selftest_mfma")
+
+
+class Outputs:
+    """Torch-owned device buffers for one forward of batch B (the dict the reference returns)."""
+
+    def __init__(self, B, F, device):
+        import torch
+        self.score_map = torch.empty(B, 1, F, F, device=device)
+        self.size_map = torch.empty(B, 2, F, F, device=device)
+        self.offset_map = torch.empty(B, 2, F, F, device=device)
+        self.pred_boxes = torch.empty(B, 4, device=device)
+        self.hann_boxes = torch.empty(B, 4, device=device)
+        self.conf = torch.empty(B, device=device)
+
+    def struct(self):
+        return VtOutputs(*[C.c_void_p(getattr(self, n).data_ptr()) for n, _ in VtOutputs._fields_])
+
+
+class Graph:
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep   # tensors the captured kernels read / write
+
+    def launch(self, stream=None):
+        _check(lib().vt_graph_launch(self._h, _stream(stream)), "vt_graph_launch")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().vt_graph_destroy(self._h)
+            self._h = None
+
+
+class Model:
+    """Owns one ``vt_model`` (weights + workspace on the current device)."""
+
+    def __init__(self, template_size, search_size, channels=48, heads=1, depth=3, head_channels=32, stride=16,
+                 max_batch=1):
+        self.cfg = VtConfig(template_size, search_size, channels, heads, depth, head_channels, stride, max_batch)
+        h = C.c_void_p()
+        _check(lib().vt_create(C.byref(self.cfg), C.byref(h)), "vt_create")
+        self._h = h
+        q = [C.c_int32() for _ in range(4)]
+        _check(lib().vt_query(self._h, *[C.byref(v) for v in q]), "vt_query")
+        self.len_z, self.len_x, self.feat_sz, self.channels = [v.value for v in q]
+        self.L = self.len_z + self.len_x
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_state_dict(self, sd: dict):
+        """sd: name -> numpy array / torch tensor, reference ckpt['net'] layout (strict=False)."""
+        keep, arr = [], (VtTensor * len(sd))()
+        n = 0
+        for k, v in sd.items():
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            v = np.asarray(v)
+            if v.dtype.kind != "f":
+                continue   # num_batches_tracked etc.
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(a)
+            arr[n] = VtTensor(k.encode(), a.ctypes.data, a.size)
+            n += 1
+        _check(lib().vt_load_weights(self._h, arr, n), "vt_load_weights")
+
+    def set_window(self, win):
+        a = np.ascontiguousarray(np.asarray(win, dtype=np.float32).reshape(-1))
+        if a.size != self.feat_sz ** 2:
+            raise VtError(f"window must have {self.feat_sz ** 2} elements")
+        _check(lib().vt_set_window(self._h, a.ctypes.data), "vt_set_window")
+
+    # ---- whole step
+    def forward(self, z, x, out: Outputs | None = None, stream=None) -> Outputs:
+        B = z.shape[0]
+        out = out or Outputs(B, self.feat_sz, z.device)
+        st = out.struct()
+        _check(lib().vt_forward(self._h, _ptr(z), _ptr(x), B, _stream(stream), C.byref(st)), "vt_forward")
+        return out
+
+    def capture(self, z, x, out: Outputs | None = None) -> tuple[Graph, Outputs]:
+        B = z.shape[0]
+        out = out or Outputs(B, self.feat_sz, z.device)
+        st = out.struct()
+        g = C.c_void_p()
+        _check(lib().vt_graph_capture(self._h, _ptr(z), _ptr(x), B, C.byref(st), C.byref(g)), "vt_graph_capture")
+        return Graph(g, (z, x, out)), out
+
+    # ---- stages
+    def stem(self, z, x, stream=None):
+        import torch
+        B = z.shape[0]
+        tok = torch.empty(B, self.L, self.channels, device=z.device)
+        _check(lib().vt_stem(self._h, _ptr(z), _ptr(x), B, _stream(stream), _ptr(tok)), "vt_stem")
+        return tok
+
+    def blocks(self, tokens, nblocks=-1, want_resid=False, stream=None, feat=None):
+        import torch
+        B = tokens.shape[0]
+        if feat is None:
+            feat = torch.empty(B, self.len_x, self.channels, device=tokens.device)
+        resid = torch.empty_like(tokens) if want_resid else None
+        _check(lib().vt_blocks(self._h, _ptr(tokens), B, nblocks, _stream(stream), _ptr(feat), _ptr(resid)), "vt_blocks")
+        return (feat, resid) if want_resid else feat
+
+    def head(self, feat, out: Outputs | None = None, stream=None) -> Outputs:
+        B = feat.shape[0]
+        out = out or Outputs(B, self.feat_sz, feat.device)
+        st = out.struct()
+        _check(lib().vt_head(self._h, _ptr(feat), B, _stream(stream), C.byref(st)), "vt_head")
+        return out
+
+    def cal_bbox(self, score, size, offset, stream=None):
+        import torch
+        B = score.shape[0]
+        bbox = torch.empty(B, 4, device=score.device)
+        mx = torch.empty(B, device=score.device)
+        _check(lib().vt_cal_bbox(self._h, _ptr(score), _ptr(size), _ptr(offset), B, _stream(stream), _ptr(bbox), _ptr(mx)),
+               "vt_cal_bbox")
+        return bbox, mx
