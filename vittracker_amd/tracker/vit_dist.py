@@ -1,0 +1,127 @@
+"""Tracker plugin: ``Vit_dist`` with the reference's ``initialize() / track()`` contract
+(``lib/test/tracker/vit_dist.py:21-156``, ``lib/test/tracker/basetracker.py:10-26``), running the
+device step on the MI355X-native library.
+
+Differences from the reference that a caller can observe (all deliberate):
+  * the device step is ONE hipGraph replay on static buffers and ONE device->host copy of five
+    floats (windowed box + confidence); the reference launches ~130 kernels and syncs in
+    ``.tolist()`` (:108-109) while leaving ``confidence`` as a 0-d device tensor (:148).  Here
+    ``confidence`` is a Python float.
+  * ``box_mask_z`` (``generate_mask_cond``, :62-66) is not computed: ``OstrackDist.forward``
+    never consumes it, and the reference's helper raises NotImplementedError for template
+    feature sizes other than 8/12/7/14 (``lib/utils/ce_utils.py:22-32``), i.e. for G128.
+  * ``params.debug`` visualisation (visdom / cv2 windows, :114-138) is not implemented.
+"""
+from __future__ import annotations
+
+import os
+
+from ..host_ops import Preprocessor, clip_box, hann2d, sample_target
+from ..model import build_ostrack_dist
+
+
+class BaseTracker:
+    """lib/test/tracker/basetracker.py:10-26 (the abstract part)."""
+
+    def __init__(self, params):
+        self.params = params
+        self.visdom = None
+
+    def predicts_segmentation_mask(self):
+        return False
+
+    def initialize(self, image, info: dict) -> dict:
+        raise NotImplementedError
+
+    def track(self, image, info: dict = None) -> dict:
+        raise NotImplementedError
+
+
+class Vit_dist(BaseTracker):
+    def __init__(self, params, dataset_name):
+        super().__init__(params)
+        import torch
+        network = build_ostrack_dist(params.cfg)
+        ckpt_path = getattr(params, "checkpoint", None)
+        if ckpt_path and os.path.isfile(ckpt_path):
+            network.load_state_dict(torch.load(ckpt_path, map_location="cpu")["net"], strict=False)  # :25
+        elif not getattr(params, "allow_synthetic_weights", False):
+            raise FileNotFoundError(
+                f"checkpoint {ckpt_path!r} not found (the reference fails in torch.load at "
+                f"lib/test/tracker/vit_dist.py:25); set params.allow_synthetic_weights=True to run on the "
+                f"seeded synthetic weights")
+        self.cfg = params.cfg
+        self.network = network.cuda()
+        self.network.eval()
+        self.preprocessor = Preprocessor()
+        self.state = None
+
+        self.feat_sz = self.cfg.TEST.SEARCH_SIZE // self.cfg.MODEL.BACKBONE.STRIDE
+        # motion constraint (:34); the same values drive the fused device-side decode
+        self.output_window = hann2d(torch.tensor([self.feat_sz, self.feat_sz]).long(), centered=True).cuda()
+        nat = self.network._native()
+        nat.set_window(self.output_window.cpu().numpy())
+
+        self.debug = getattr(params, "debug", 0)
+        self.frame_id = 0
+        self.save_all_boxes = params.save_all_boxes
+        self.z_dict1 = {}
+
+        # static device buffers + captured graph of the whole device step
+        tz, tx = self.params.template_size, self.params.search_size
+        self._z = torch.zeros(1, 3, tz, tz, device="cuda")
+        self._x = torch.zeros(1, 3, tx, tx, device="cuda")
+        self._graph, self._out = nat.capture(self._z, self._x)
+        self._rec = torch.empty(5, device="cuda")
+        self._rec_host = torch.empty(5).pin_memory()
+
+    def initialize(self, image, info: dict):
+        z_patch_arr, resize_factor, z_amask_arr = sample_target(image, info["init_bbox"], self.params.template_factor,
+                                                                output_sz=self.params.template_size)
+        self.z_patch_arr = z_patch_arr
+        template = self.preprocessor.process(z_patch_arr, z_amask_arr)
+        self.z_dict1 = template
+        self._z.copy_(template.tensors)
+        self.box_mask_z = None
+        self.state = info["init_bbox"]
+        self.frame_id = 0
+        if self.save_all_boxes:
+            return {"all_boxes": info["init_bbox"] * 1}
+
+    def track(self, image, info: dict = None):
+        import torch
+        H, W, _ = image.shape
+        self.frame_id += 1
+        x_patch_arr, resize_factor, x_amask_arr = sample_target(image, self.state, self.params.search_factor,
+                                                                output_sz=self.params.search_size)
+        search = self.preprocessor.process(x_patch_arr, x_amask_arr)
+        self._x.copy_(search.tensors)
+
+        # network.forward + hann window + cal_bbox (:86-105) = one graph replay
+        self._graph.launch()
+        self._rec[:4].copy_(self._out.hann_boxes.view(-1))
+        self._rec[4:].copy_(self._out.conf)
+        self._rec_host.copy_(self._rec, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        rec = self._rec_host
+
+        # Baseline: mean over the (single) predicted box, scaled back to crop pixels (:107-109)
+        pred_box = (rec[:4].view(1, 4).mean(dim=0) * self.params.search_size / resize_factor).tolist()
+        self.state = clip_box(self.map_box_back(pred_box, resize_factor), H, W, margin=10)
+
+        if self.save_all_boxes:
+            return {"target_bbox": self.state, "all_boxes": list(self.state)}
+        return {"target_bbox": self.state, "confidence": float(rec[4])}
+
+    def map_box_back(self, pred_box: list, resize_factor: float):
+        """:150-156"""
+        cx_prev, cy_prev = self.state[0] + 0.5 * self.state[2], self.state[1] + 0.5 * self.state[3]
+        cx, cy, w, h = pred_box
+        half_side = 0.5 * self.params.search_size / resize_factor
+        cx_real = cx + (cx_prev - half_side)
+        cy_real = cy + (cy_prev - half_side)
+        return [cx_real - 0.5 * w, cy_real - 0.5 * h, w, h]
+
+
+def get_tracker_class():
+    return Vit_dist
