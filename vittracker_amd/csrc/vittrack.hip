@@ -123,6 +123,25 @@ std::vector<float> pack_conv_groups(const std::vector<double>& w, int cout, int 
     return out;
 }
 
+// folded conv [cout][cin][3][3] -> MFMA A-operand images [oc_tile][chunk][64 lanes][4] for the
+// implicit GEMM of vt_head.h: element r of lane l of (ot, c) = w[oc = 16 ot + (l & 15)][ic = 4 icq + r][tap]
+// with quad Q = 4 c + (l >> 4), (tap, icq) = divmod(Q, cin / 4); zero beyond cout or 9 * cin / 4 quads.
+void pack_conv_image(const std::vector<double>& w, int cout, int cin, float* dst) {
+    const int nq = cin / 4, nqt = 9 * nq, nch = (nqt + 3) / 4, not_ = (cout + 15) / 16;
+    for (int ot = 0; ot < not_; ++ot)
+        for (int c = 0; c < nch; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                    const int oc = 16 * ot + (l & 15), Q = 4 * c + (l >> 4);
+                    float v = 0.f;
+                    if (oc < cout && Q < nqt) {
+                        const int tap = Q / nq, ic = 4 * (Q % nq) + r;
+                        v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
+                    }
+                    dst[(((size_t)ot * nch + c) * 64 + l) * 4 + r] = v;
+                }
+}
+
 // nn.Linear weight (OUT, IN) -> MFMA operand images [OUT/16][IN/16][64 lanes][4]:
 // element r of lane l of tile (ot, c) = W[16 ot + (l & 15)][16 c + 4 (l >> 4) + r]   (vt_common.h)
 void pack_linear_image(const float* W, int OUT, int IN, float* dst) {
@@ -224,10 +243,10 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* hann = (o && o->hann_boxes) ? o->hann_boxes : m->hann.p;
     float* conf = (o && o->conf) ? o->conf : m->conf.p;
     if (m->F == 8) {
-        hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::HeadLds<8>::FLOATS * sizeof(float), st,
+        hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
                            feat, m->head.p, score, size, offset);
     } else if (m->F == 16) {
-        hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::HeadLds<16>::FLOATS * sizeof(float),
+        hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::Geo<16>::LDS_BYTES,
                            st, feat, m->head.p, score, size, offset);
     } else {
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
@@ -304,7 +323,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(vth::HeadLds<16>::FLOATS * sizeof(float)));
+                                    (int)(vth::Geo<16>::LDS_BYTES));
         if (e != hipSuccess) rc = fail(VT_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (rc) {
@@ -389,8 +408,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             const std::string cn = std::string("box_head.conv") + std::to_string(i + 1) + "_" + towers[t];
             std::vector<double> w, b;
             if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, chans[i + 1], chans[i], w, b))) return rc;
-            std::vector<float> pk = pack_conv_groups(w, chans[i + 1], chans[i], chans[i + 1] / 4);
-            std::memcpy(dst + woff[i], pk.data(), pk.size() * sizeof(float));
+            pack_conv_image(w, chans[i + 1], chans[i], dst + woff[i]);
             for (int o = 0; o < chans[i + 1]; ++o) dst[boff[i] + o] = (float)b[o];
         }
         const int nout = t == 0 ? 1 : 2;

@@ -4,10 +4,17 @@
 // CenterPredictor.get_score_map / forward / cal_bbox (lib/models/layers/head.py:130-201) and the
 // tracker's Hann-windowed second decode (lib/test/tracker/vit_dist.py:103-105).
 //
-// v1 towers kernel: one workgroup per (frame, tower).  The F x F x 48 feature map and every
-// intermediate live in LDS as zero-bordered channel planes, so a 3x3 tap is a constant address
-// offset and needs no bounds test.  Wave w owns output-channel group w of each layer; its folded
-// conv+BN weights are wave-uniform ([group][tap][cin][OCG]) and arrive as scalar operands.
+// Towers kernel: one workgroup per (frame, tower); every 3x3 conv (+ folded BN + ReLU) is an
+// implicit GEMM on v_mfma_f32_16x16x4_f32 with the folded weights as the A operand (rows = output
+// channels) and the activations as the B operand (columns = 16 output pixels), so a result tile is
+// already "4 consecutive channels of one pixel per lane" = the storage unit of the next layer.
+//
+// LDS maps are QUAD-PLANAR: float4 map[icq][pix] = channels 4*icq..4*icq+3 of padded pixel pix,
+// pix = row * P + col over a zero-bordered (F+2) x (F+2) grid, plane size NPIX a multiple of 16.
+// A 3x3 tap is a constant pixel offset (no bounds tests), and the B operand of k-chunk c for lane
+// (px = lane & 15, q = lane >> 4) is ONE ds_read_b128 at quad Q = 4c + q -> (tap, icq) =
+// divmod(Q, CIN/4): 16 consecutive pixels per quarter-wave, conflict-free at F = 16
+// (tools/lds_conflicts.py).
 #pragma once
 #include "vt_common.h"
 
@@ -16,66 +23,87 @@ namespace vth {
 constexpr int C = 48;   // head input channels
 constexpr int W1 = 32;  // MODEL.HEAD.NUM_CHANNELS
 
-// packed per-tower offsets (floats): 4 folded 3x3 layers then the 1x1
-constexpr int O_W1 = 0;                          // [4][9][48][8]
-constexpr int O_B1 = O_W1 + 9 * C * W1;          // 32
-constexpr int O_W2 = O_B1 + W1;                  // [4][9][32][4]
-constexpr int O_B2 = O_W2 + 9 * W1 * 16;         // 16
-constexpr int O_W3 = O_B2 + 16;                  // [4][9][16][2]
-constexpr int O_B3 = O_W3 + 9 * 16 * 8;          // 8
-constexpr int O_W4 = O_B3 + 8;                   // [4][9][8][1]
-constexpr int O_B4 = O_W4 + 9 * 8 * 4;           // 4
-constexpr int O_W5 = O_B4 + 4;                   // [2][4] (ctr uses row 0)
-constexpr int O_B5 = O_W5 + 8;                   // 2
-constexpr int TOWER_STRIDE = ((O_B5 + 2 + 3) / 4) * 4;
+constexpr int nchunks(int cin) { return (9 * (cin / 4) + 3) / 4; }
+constexpr int ntiles(int cout) { return (cout + 15) / 16; }
 
-// One 3x3 stride-1 layer + ReLU on LDS planes.  NPW = 64-pixel groups per map (F*F/64).
-template <int CIN, int COUT, int F, int NPS>
-__device__ __forceinline__ void conv_relu_layer(const float* in_s, float* out_s, const float* __restrict__ w,
-                                                const float* __restrict__ bias, int wave, int lane) {
-    constexpr int OCG = COUT / 4;
-    constexpr int NPW = (F * F) / 64;
-    constexpr int P = F + 2;
-    int pc[NPW];
-#pragma unroll
-    for (int k = 0; k < NPW; ++k) {
-        const int pix = k * 64 + lane;
-        pc[k] = (pix / F + 1) * P + (pix % F) + 1;
+// packed per-tower parameter offsets (floats). Images: [oc_tile][chunk][64 lanes][4];
+// biases padded to 16 * tiles.
+constexpr int O_W1 = 0;
+constexpr int O_B1 = O_W1 + ntiles(32) * nchunks(48) * 256;
+constexpr int O_W2 = O_B1 + 32;
+constexpr int O_B2 = O_W2 + ntiles(16) * nchunks(32) * 256;
+constexpr int O_W3 = O_B2 + 16;
+constexpr int O_B3 = O_W3 + ntiles(8) * nchunks(16) * 256;
+constexpr int O_W4 = O_B3 + 16;
+constexpr int O_B4 = O_W4 + ntiles(4) * nchunks(8) * 256;
+constexpr int O_W5 = O_B4 + 16;   // [2][4] (ctr uses row 0)
+constexpr int O_B5 = O_W5 + 8;    // 2 (+2 pad)
+constexpr int TOWER_STRIDE = O_B5 + 4;
+static_assert(TOWER_STRIDE % 4 == 0 && O_W2 % 4 == 0 && O_W3 % 4 == 0 && O_W4 % 4 == 0, "16B alignment");
+
+template <int F>
+struct Geo {
+    static constexpr int P = F + 2;                          // padded row pitch (pixels)
+    static constexpr int NPIX = ((P * P + 15) / 16) * 16;    // plane size (pixels)
+    static constexpr int NT = F * F / 16;                    // 16-pixel output tiles
+    static constexpr int NPT = NT / 4;                       // tiles per wave (4 waves)
+    static constexpr int QUADS = C / 4 + W1 / 4 + 4;         // in(12) + ping(8) + pong(4)
+    static constexpr int LDS_BYTES = QUADS * NPIX * 16;
+    // padded pixel index of this lane's output pixel in tile t, minus one row and one column
+    // (= the address of tap (0,0))
+    __device__ static __forceinline__ int tap00(int t, int lane) {
+        const int px = lane & 15;
+        if constexpr (F == 16) return t * P + px;
+        else return (2 * t + (px >> 3)) * P + (px & 7);
     }
-    float acc[NPW][OCG];
+};
+
+// One 3x3 stride-1 conv + bias + ReLU between two LDS maps on MFMA.
+template <int CIN, int COUT, int F>
+__device__ __forceinline__ void conv3x3_relu_mfma(const f4* in_map, f4* out_map, const float* __restrict__ wimg,
+                                                  const float* __restrict__ bias, int wave, int lane) {
+    using G = Geo<F>;
+    constexpr int NQ = CIN / 4, NQT = 9 * NQ, NCH = nchunks(CIN), NOT = ntiles(COUT), NPT = G::NPT;
+    const int q = lane >> 4;
+    int base[NPT];
 #pragma unroll
-    for (int k = 0; k < NPW; ++k)
+    for (int i = 0; i < NPT; ++i) base[i] = G::tap00(wave + 4 * i, lane);
+    f4 acc[NPT][NOT];
 #pragma unroll
-        for (int j = 0; j < OCG; ++j) acc[k][j] = bias[wave * OCG + j];
-    const float* __restrict__ wg = w + (size_t)wave * 9 * CIN * OCG;
+    for (int ot = 0; ot < NOT; ++ot) {
+        const f4 bv = ld4(bias + 16 * ot + 4 * q);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (tap / 3 - 1) * P + (tap % 3 - 1);
-#pragma unroll 4
-        for (int ic = 0; ic < CIN; ++ic) {
-            float v[NPW];
+        for (int i = 0; i < NPT; ++i) acc[i][ot] = bv;
+    }
+#pragma unroll 3
+    for (int c = 0; c < NCH; ++c) {
+        int Q = 4 * c + q;
+        Q = Q < NQT ? Q : NQT - 1;          // pad quads: weights are zero, any finite B will do
+        const int tap = Q / NQ, icq = Q - tap * NQ;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int off = icq * G::NPIX + dy * G::P + dx;
+        f4 bop[NPT];
 #pragma unroll
-            for (int k = 0; k < NPW; ++k) v[k] = in_s[ic * NPS + pc[k] + toff];
+        for (int i = 0; i < NPT; ++i) bop[i] = in_map[off + base[i]];
 #pragma unroll
-            for (int j = 0; j < OCG; ++j) {
-                const float ww = wg[(tap * CIN + ic) * OCG + j];
+        for (int ot = 0; ot < NOT; ++ot) {
+            const f4 a = ld4(wimg + ((size_t)(ot * NCH + c) * 64 + lane) * 4);
 #pragma unroll
-                for (int k = 0; k < NPW; ++k) acc[k][j] = fmaf(v[k], ww, acc[k][j]);
-            }
+            for (int i = 0; i < NPT; ++i) acc[i][ot] = mfma4(a, bop[i], acc[i][ot]);
         }
     }
 #pragma unroll
-    for (int k = 0; k < NPW; ++k)
+    for (int ot = 0; ot < NOT; ++ot) {
+        if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
 #pragma unroll
-        for (int j = 0; j < OCG; ++j) out_s[(wave * OCG + j) * NPS + pc[k]] = fmaxf(acc[k][j], 0.f);
+            for (int i = 0; i < NPT; ++i) {
+                f4 v = acc[i][ot];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                out_map[(4 * ot + q) * G::NPIX + base[i] + G::P + 1] = v;
+            }
+        }
+    }
 }
-
-template <int F>
-struct HeadLds {
-    static constexpr int P = F + 2;
-    static constexpr int NPS = ((P * P + 3) / 4) * 4;        // plane stride (floats)
-    static constexpr int FLOATS = (C + W1 + 16) * NPS;       // in(48) + ping(32) + pong(16)
-};
 
 // grid (B, 3): tower 0 = ctr, 1 = offset, 2 = size.   feat: (B, F*F, 48) normalised search tokens.
 template <int F>
@@ -83,48 +111,41 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
                                                           const float* __restrict__ hw,
                                                           float* __restrict__ score, float* __restrict__ size,
                                                           float* __restrict__ offset) {
-    constexpr int NPS = HeadLds<F>::NPS, P = F + 2;
+    using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* in_s = sm;
-    float* a_s = in_s + C * NPS;
-    float* b_s = a_s + W1 * NPS;
+    f4* in_map = reinterpret_cast<f4*>(sm);            // 12 quads
+    f4* m1 = in_map + (C / 4) * G::NPIX;               // 8 quads
+    f4* m2 = m1 + (W1 / 4) * G::NPIX;                  // 4 quads
     const int b = blockIdx.x, t = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
 
-    for (int i = threadIdx.x; i < HeadLds<F>::FLOATS; i += 256) sm[i] = 0.f;
+    for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += 256) in_map[i] = splat4(0.f);
     __syncthreads();
-    // (B,HW,C) -> (C,F,F) planes: f[c][p][q] = feat[b][p*F+q][c]   (vit_dist.py:126-129)
+    // (B,HW,C) tokens -> quad planes: map[c/4][p][q] = feat[b][p*F+q][c..c+3]   (vit_dist.py:126-129)
     for (int i = threadIdx.x; i < F * F * (C / 4); i += 256) {
-        const int pix = i / (C / 4), c4 = i % (C / 4);
-        const f4 v = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * c4);
-        const int pc = (pix / F + 1) * P + (pix % F) + 1;
-        in_s[(4 * c4 + 0) * NPS + pc] = v.x;
-        in_s[(4 * c4 + 1) * NPS + pc] = v.y;
-        in_s[(4 * c4 + 2) * NPS + pc] = v.z;
-        in_s[(4 * c4 + 3) * NPS + pc] = v.w;
+        const int icq = i / (F * F), pix = i % (F * F);
+        in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] =
+            ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
     }
     __syncthreads();
-    conv_relu_layer<C, W1, F, NPS>(in_s, a_s, tw + O_W1, tw + O_B1, wave, lane);
+    conv3x3_relu_mfma<C, W1, F>(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
     __syncthreads();
-    conv_relu_layer<W1, 16, F, NPS>(a_s, b_s, tw + O_W2, tw + O_B2, wave, lane);
+    conv3x3_relu_mfma<W1, 16, F>(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
     __syncthreads();
-    conv_relu_layer<16, 8, F, NPS>(b_s, a_s, tw + O_W3, tw + O_B3, wave, lane);
+    conv3x3_relu_mfma<16, 8, F>(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
     __syncthreads();
-    conv_relu_layer<8, 4, F, NPS>(a_s, b_s, tw + O_W4, tw + O_B4, wave, lane);
+    conv3x3_relu_mfma<8, 4, F>(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
     __syncthreads();
     // 1x1 conv + activation (head.py:187,194,200-201)
     for (int pix = threadIdx.x; pix < F * F; pix += 256) {
-        const int pc = (pix / F + 1) * P + (pix % F) + 1;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = b_s[c * NPS + pc];
+        const f4 v = m2[(pix / F + 1) * G::P + (pix % F) + 1];
         const int nout = (t == 0) ? 1 : 2;
         for (int o = 0; o < nout; ++o) {
+            const f4 w5 = ld4(tw + O_W5 + 4 * o);
             float y = tw[O_B5 + o];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) y = fmaf(v[c], tw[O_W5 + o * 4 + c], y);
+            y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
             if (t == 0) score[(size_t)b * F * F + pix] = sigmoid_clamped(y);
             else if (t == 2) size[((size_t)b * 2 + o) * F * F + pix] = sigmoid_clamped(y);
             else offset[((size_t)b * 2 + o) * F * F + pix] = y;
@@ -138,7 +159,7 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 }
 
 // cal_bbox on the raw score and on window * score in one pass; one wave per frame.
-// Any of pred / hann / conf / maxscore may be null.  window may be null (then hann is skipped).
+// Any of pred / hann / conf may be null.  window may be null (then hann is skipped).
 __global__ __launch_bounds__(64) void decode_kernel(const float* __restrict__ score, const float* __restrict__ size,
                                                     const float* __restrict__ offset,
                                                     const float* __restrict__ window, int F,
