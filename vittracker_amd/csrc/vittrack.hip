@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -48,7 +49,6 @@ struct DevBuf {
 };
 
 constexpr int STEM_CH[5] = {3, 6, 12, 24, 48};
-constexpr int STEM_OCG[4] = {6, 12, 12, 12};   // output channels per thread, per layer
 
 }  // namespace
 
@@ -63,7 +63,7 @@ struct vt_model {
     DevBuf head;                     // 3 * TOWER_STRIDE
     DevBuf window;                   // F*F
     // workspace sized for max_batch
-    DevBuf act_x[3], act_z[3];       // NHWC stem intermediates
+    DevBuf act_x, act_z;             // layer-2 activations, NHWC(12)
     DevBuf tokens, feat;
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
@@ -174,28 +174,6 @@ std::vector<float> hann2d(int F) {
 }
 
 // ------------------------------------------------------------------------------------- launches
-template <int CIN, int COUT, int OCG, bool NCHW, bool HSW, bool TOK>
-void launch_conv(hipStream_t st, const float* in, const float* w, const float* b, float* out, int B, int H, int W,
-                 const float* pos, int tok_off, int L) {
-    const int npix = B * (H / 2) * (W / 2);
-    dim3 grid((npix + 255) / 256, COUT / OCG);
-    hipLaunchKernelGGL((vts::conv_s2_kernel<CIN, COUT, OCG, NCHW, HSW, TOK>), grid, dim3(256), 0, st, in, w, b, out, B,
-                       H, W, pos, tok_off, L);
-}
-
-int stem_one(vt_model* m, hipStream_t st, const float* img, int T, DevBuf* act, const float* pos, int tok_off, int B,
-             float* tokens) {
-    launch_conv<3, 6, 6, true, true, false>(st, img, m->stem_w[0].p, m->stem_b[0].p, act[0].p, B, T, T, nullptr, 0, 0);
-    launch_conv<6, 12, 12, false, true, false>(st, act[0].p, m->stem_w[1].p, m->stem_b[1].p, act[1].p, B, T / 2, T / 2,
-                                               nullptr, 0, 0);
-    launch_conv<12, 24, 12, false, true, false>(st, act[1].p, m->stem_w[2].p, m->stem_b[2].p, act[2].p, B, T / 4, T / 4,
-                                                nullptr, 0, 0);
-    launch_conv<24, 48, 12, false, false, true>(st, act[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, B, T / 8, T / 8,
-                                                pos, tok_off, m->L);
-    HIP_TRY(hipGetLastError());
-    return VT_OK;
-}
-
 int check_ready(vt_model* m, int B) {
     if (!m) return fail(VT_ERR_ARG, "null model");
     if (!m->weights_loaded) return fail(VT_ERR_STATE, "vt_load_weights has not been called");
@@ -204,10 +182,33 @@ int check_ready(vt_model* m, int B) {
     return VT_OK;
 }
 
+// Band sizes per crop side.  stem_a: r2 layer-2 rows per workgroup (256 output pixels);
+// stem_b: r4 token rows per workgroup (LDS <= ~50 KB so three workgroups share a CU).
+struct StemPlan { int r2, r4; };
+StemPlan stem_plan(int T) {
+    switch (T) {
+        case 64: return {16, 4};    // layer-2 map 16x16, tokens 4x4: one band each
+        case 128: return {8, 4};    // 32x32 -> 4 bands; tokens 8x8 -> 2 bands
+        case 256: return {4, 2};    // 64x64 -> 16 bands; tokens 16x16 -> 8 bands
+        default: return {0, 0};
+    }
+}
+
 int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens) {
-    int rc;
-    if ((rc = stem_one(m, st, z, m->cfg.template_size, m->act_z, m->pos_z.p, 0, B, tokens))) return rc;
-    return stem_one(m, st, x, m->cfg.search_size, m->act_x, m->pos_x.p, m->len_z, B, tokens);
+    const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
+    const StemPlan px = stem_plan(Tx), pz = stem_plan(Tz);
+    vts::CropA ax{x, m->act_x.p, Tx, px.r2, (Tx / 4) / px.r2}, az{z, m->act_z.p, Tz, pz.r2, (Tz / 4) / pz.r2};
+    const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
+    hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
+                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p);
+    HIP_TRY(hipGetLastError());
+    vts::CropB bx{m->act_x.p, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
+    vts::CropB bz{m->act_z.p, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
+    const size_t lds_b = std::max(vts::stem_b_lds_bytes(Tx / 4, px.r4), vts::stem_b_lds_bytes(Tz / 4, pz.r4));
+    hipLaunchKernelGGL(vts::stem_b_kernel, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
+                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
 }
 
 template <int NT, int NW, int TPW>
@@ -300,11 +301,8 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     const size_t B = (size_t)cfg->max_batch;
     int rc = VT_OK;
     auto A = [&](DevBuf& d, size_t n) { if (!rc) rc = d.alloc(n); };
-    for (int i = 0; i < 3; ++i) {
-        const size_t sx = (size_t)(cfg->search_size >> (i + 1)), sz = (size_t)(cfg->template_size >> (i + 1));
-        A(m->act_x[i], B * sx * sx * STEM_CH[i + 1]);
-        A(m->act_z[i], B * sz * sz * STEM_CH[i + 1]);
-    }
+    A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
+    A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
     A(m->tokens, B * m->L * 48);
     A(m->feat, B * m->len_x * 48);
     A(m->score, B * m->len_x);
@@ -337,7 +335,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
 void vt_destroy(vt_model* m) {
     if (!m) return;
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
-    for (int i = 0; i < 3; ++i) { m->act_x[i].release(); m->act_z[i].release(); }
+    m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
@@ -357,8 +355,17 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         const std::string p = "patch_embed.net." + std::to_string(2 * i);
         std::vector<double> w, b;
         if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
-        if ((rc = upload(m->stem_w[i], pack_conv_groups(w, STEM_CH[i + 1], STEM_CH[i], STEM_OCG[i])))) return rc;
-        if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+        if (i < 2) {   // VALU layers: [tap][cin][cout], weights become scalar operands
+            if ((rc = upload(m->stem_w[i], pack_conv_groups(w, STEM_CH[i + 1], STEM_CH[i], STEM_CH[i + 1])))) return rc;
+            if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+        } else {       // MFMA layers: A-operand images, bias padded to whole 16-channel tiles
+            const int tiles = (STEM_CH[i + 1] + 15) / 16, nch = (9 * (STEM_CH[i] / 4) + 3) / 4;
+            std::vector<float> img((size_t)tiles * nch * 256), bias((size_t)tiles * 16, 0.f);
+            pack_conv_image(w, STEM_CH[i + 1], STEM_CH[i], img.data());
+            for (int o = 0; o < STEM_CH[i + 1]; ++o) bias[o] = (float)b[o];
+            if ((rc = upload(m->stem_w[i], img))) return rc;
+            if ((rc = upload(m->stem_b[i], bias))) return rc;
+        }
     }
     const float* p;
     if ((rc = need(tm, "pos_embed_z", (int64_t)m->len_z * C, &p))) return rc;

@@ -4,96 +4,278 @@
 // Replaces Conv2d_BN / b16 / LevitPatchEmbedding.forward and the pos-embed add + cat of
 // OstrackDist.forward (lib/models/vit_dist/vit_dist.py:10-54,78-84).
 //
-// v1 kernels: direct convolution, one thread per output pixel and output-channel group.  The
-// folded weights of a group are wave-uniform, laid out [group][tap][cin][OCG] so the compiler
-// fetches them with scalar loads and feeds them to v_fma_f32 as SGPR operands; activations
-// between layers are channels-last (NHWC) so a thread's CIN inputs per tap are one or two
-// 16-byte loads.  The first layer reads the NCHW crops the boundary hands over.
+// Two kernels, both crops (z and x) in the same launch:
+//
+//  stem_a  layers 1+2, the HBM-streaming half.  One workgroup per (frame, crop, band of R2 layer-2
+//          rows).  Layer 1 (3 -> 6) reads the NCHW crop straight from HBM -- each wave-instruction
+//          covers whole 512/1024-byte image rows with float4 loads, two output pixels per thread --
+//          and leaves its 2*R2+1 output rows in LDS (never in HBM).  Layer 2 (6 -> 12) reads them
+//          back with unit-stride ds_read_b32 thanks to a column-parity split (even | odd halves per
+//          row) and writes NHWC(12).  Both layers run on the VALU with their folded weights as
+//          wave-uniform SGPR operands: at 6 / 12 output channels an MFMA tile would be 37-75 % padding.
+//
+//  stem_b  layers 3+4 on v_mfma_f32_16x16x4_f32 as implicit GEMMs (weights = A operand, 16 output
+//          pixels = B operand columns), one workgroup per (frame, crop, band of R4 token rows).
+//          Inputs live in LDS as parity-split QUAD-PLANAR maps: float4 map[icq][row][even|odd col],
+//          so the stride-2 taps of 16 consecutive output pixels are 16 consecutive float4 and the B
+//          operand of a k-chunk is one ds_read_b128.  Layer 3's result tile is written straight
+//          into layer 4's input map; layer 4 adds the pos-embed and stores token rows.
 #pragma once
 #include "vt_common.h"
 
 namespace vts {
 
-template <int CIN, bool NCHW>
-__device__ __forceinline__ void load_pixel(const float* __restrict__ in, int b, int iy, int ix, int H, int W,
-                                           float (&v)[CIN]) {
-    if constexpr (NCHW) {
+struct CropA {            // one crop for stem_a
+    const float* in;      // (B, 3, T, T) NCHW
+    float* out;           // (B, T/4, T/4, 12) NHWC
+    int T;                // crop side
+    int r2;               // layer-2 rows per band
+    int bands;            // (T/4) / r2
+};
+
+// LDS floats stem_a needs for a crop of side T with r2 rows per band
+__host__ __device__ constexpr int stem_a_lds_floats(int T, int r2) { return 6 * (2 * r2 + 1) * (T / 2 + 1); }
+
+__global__ __launch_bounds__(256) void stem_a_kernel(CropA cx, CropA cz, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2) {
+    extern __shared__ __attribute__((aligned(16))) float l1[];   // [6][NR1][PITCH]
+    const int per = cx.bands + cz.bands;
+    const int b = blockIdx.x / per;
+    int k = blockIdx.x - b * per;
+    const bool is_z = k >= cx.bands;
+    if (is_z) k -= cx.bands;
+    const float* __restrict__ in = is_z ? cz.in : cx.in;
+    float* __restrict__ out = is_z ? cz.out : cx.out;
+    const int T = is_z ? cz.T : cx.T;
+    const int R2 = is_z ? cz.r2 : cx.r2;
+    const int W1 = T >> 1, HALF = T >> 2, PITCH = W1 + 1, NR1 = 2 * R2 + 1, W2 = T >> 2;
+    const int p0 = k * R2;                       // first layer-2 row of this band
+    const int plane = NR1 * PITCH;
+
+    // ---- layer 1: rows 2*p0-1 .. 2*p0+2*R2-1 of the layer-1 map, two pixels per thread ----------
+    for (int i = threadIdx.x; i < NR1 * HALF; i += 256) {
+        const int lr = i / HALF, qp = i - lr * HALF;
+        const int p1 = 2 * p0 - 1 + lr;
+        float a0[6], a1[6];
+        if (p1 < 0) {                            // row -1 of the layer-1 map = layer 2's zero padding
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) v[c] = in[(((size_t)b * CIN + c) * H + iy) * W + ix];
-    } else {
-        const float* p = in + (((size_t)b * H + iy) * W + ix) * CIN;
-        if constexpr (CIN % 4 == 0) {
-#pragma unroll
-            for (int c = 0; c < CIN; c += 4) {
-                f4 t = ld4(p + c);
-                v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
-            }
+            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = 0.f;
         } else {
 #pragma unroll
-            for (int c = 0; c < CIN; c += 2) {
-                float2 t = *reinterpret_cast<const float2*>(p + c);
-                v[c] = t.x; v[c + 1] = t.y;
+            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = 2 * p1 + r - 1;
+                if (iy < 0) continue;            // zero padding: the tap adds exactly 0
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* row = in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp;
+                    const f4 v = ld4(row);
+                    const float vm = qp > 0 ? row[-1] : 0.f;
+                    const float t0[3] = {vm, v.x, v.y}, t1[3] = {v.y, v.z, v.w};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const float ww = w1[((r * 3 + s) * 3 + c) * 6 + j];
+                            a0[j] = fmaf(t0[s], ww, a0[j]);
+                            a1[j] = fmaf(t1[s], ww, a1[j]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]); a1[j] = hardswish(a1[j]); }
+        }
+        float* dst = l1 + lr * PITCH;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            dst[j * plane + qp] = a0[j];                 // even column 2*qp
+            dst[j * plane + HALF + 1 + qp] = a1[j];      // odd column 2*qp+1
+        }
+    }
+    for (int i = threadIdx.x; i < 6 * NR1; i += 256) l1[i * PITCH + HALF] = 0.f;   // column -1
+    __syncthreads();
+
+    // ---- layer 2: one output pixel x 12 channels per thread ------------------------------------
+    for (int i = threadIdx.x; i < R2 * W2; i += 256) {
+        const int pl = i / W2, q = i - pl * W2;
+        float acc[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[j] = b2[j];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* rowp = l1 + (2 * pl + r) * PITCH + q;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float* pc = rowp + c * plane;
+                const float t[3] = {pc[HALF], pc[0], pc[HALF + 1]};   // columns 2q-1, 2q, 2q+1
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc[j] = fmaf(t[s], w2[((r * 3 + s) * 6 + c) * 12 + j], acc[j]);
             }
         }
+        float* dst = out + (((size_t)b * W2 + p0 + pl) * W2 + q) * 12;
+#pragma unroll
+        for (int j = 0; j < 12; j += 4)
+            st4(dst + j, f4{hardswish(acc[j]), hardswish(acc[j + 1]), hardswish(acc[j + 2]), hardswish(acc[j + 3])});
     }
 }
 
-// out: NHWC (B, H/2, W/2, COUT), or with TOKENS the token matrix rows [tok_off, tok_off + HoWo)
-// of (B, L, COUT) with pos (HoWo, COUT) added.
-template <int CIN, int COUT, int OCG, bool NCHW, bool HSWISH, bool TOKENS>
-__global__ __launch_bounds__(256) void conv_s2_kernel(const float* __restrict__ in, const float* __restrict__ wp,
-                                                      const float* __restrict__ bp, float* __restrict__ out,
-                                                      int B, int H, int W, const float* __restrict__ pos,
-                                                      int tok_off, int L) {
-    static_assert(COUT % OCG == 0, "group size");
-    const int Ho = H >> 1, Wo = W >> 1;
-    const int g = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= B * Ho * Wo) return;
-    const int qx = idx % Wo, py = (idx / Wo) % Ho, b = idx / (Wo * Ho);
+// ------------------------------------------------------------------------------------------ stem_b
+struct CropB {
+    const float* in;      // (B, S2, S2, 12) NHWC, S2 = T/4
+    const float* pos;     // (S4*S4, 48)
+    int S2;               // layer-2 map side
+    int r4;               // token rows per band
+    int bands;            // (S2/4) / r4
+    int tok_off;          // first token row of this crop in the (B, L, 48) matrix
+};
 
-    float acc[OCG];
-#pragma unroll
-    for (int j = 0; j < OCG; ++j) acc[j] = bp[g * OCG + j];
-    const float* __restrict__ wg = wp + (size_t)g * 9 * CIN * OCG;
+constexpr int round16(int v) { return (v + 15) & ~15; }
+// plane sizes (pixels) of the two LDS maps for a band of r4 token rows of a crop with S2
+__host__ __device__ constexpr int stem_b_npix2(int S2, int r4) { return round16((4 * r4 + 3) * (S2 + 1)); }
+__host__ __device__ constexpr int stem_b_npix3(int S2, int r4) { return round16((2 * r4 + 1) * (S2 / 2 + 1)); }
+__host__ __device__ constexpr int stem_b_lds_bytes(int S2, int r4) {
+    return (3 * stem_b_npix2(S2, r4) + 6 * stem_b_npix3(S2, r4)) * 16;
+}
 
+constexpr int nchunks_q(int nq) { return (9 * nq + 3) / 4; }
+
+// Implicit-GEMM stride-2 3x3 conv over a parity-split quad-planar LDS map.
+//   in_map[icq * npix_in + row * pitch_in + (col odd ? half_in + 1 + col/2 : col/2)], local row 0
+//   = the row above the band's first needed row (zero row at the image top), entry half_in = col -1.
+// Output pixels are numbered row-major over (rows_out x wout); tile t = pixels 16t .. 16t+15.
+// Each wave takes tiles wave, wave+4, ... in groups of NPT; store(t_index_in_group, tile, ot, value).
+template <int NQ, int NOT, int NPT, typename Store>
+__device__ __forceinline__ void conv_s2_mfma(const f4* in_map, int npix_in, int pitch_in, int half_in, int wout_log2,
+                                             int ntiles, const float* __restrict__ wimg,
+                                             const float* __restrict__ bias, int wave, int lane, Store store) {
+    constexpr int NQT = 9 * NQ, NCH = nchunks_q(NQ);
+    const int q = lane >> 4, px = lane & 15;
+    for (int t0 = wave; t0 < ntiles; t0 += 4 * NPT) {
+        int base[NPT];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int iy = 2 * py + r - 1;
-        if (iy < 0 || iy >= H) continue;      // zero padding: skipped taps add exactly 0
+        for (int i = 0; i < NPT; ++i) {
+            int t = t0 + 4 * i;
+            t = t < ntiles ? t : ntiles - 1;             // clamped tiles are computed but not stored
+            const int op = 16 * t + px;
+            const int y = op >> wout_log2, x = op - (y << wout_log2);
+            base[i] = 2 * y * pitch_in + x;
+        }
+        f4 acc[NPT][NOT];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int ix = 2 * qx + s - 1;
-            if (ix < 0 || ix >= W) continue;
-            float v[CIN];
-            load_pixel<CIN, NCHW>(in, b, iy, ix, H, W, v);
-            const float* __restrict__ wt = wg + (r * 3 + s) * CIN * OCG;
+        for (int ot = 0; ot < NOT; ++ot) {
+            const f4 bv = ld4(bias + 16 * ot + 4 * q);
 #pragma unroll
-            for (int c = 0; c < CIN; ++c)
+            for (int i = 0; i < NPT; ++i) acc[i][ot] = bv;
+        }
+#pragma unroll 2
+        for (int c = 0; c < NCH; ++c) {
+            int Q = 4 * c + q;
+            Q = Q < NQT ? Q : NQT - 1;
+            const int tap = Q / NQ, icq = Q - tap * NQ;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int off = icq * npix_in + dy * pitch_in + (dx == 1 ? 0 : (dx == 0 ? half_in : half_in + 1));
+            f4 bop[NPT];
 #pragma unroll
-                for (int j = 0; j < OCG; ++j) acc[j] = fmaf(v[c], wt[c * OCG + j], acc[j]);
+            for (int i = 0; i < NPT; ++i) bop[i] = in_map[off + base[i]];
+#pragma unroll
+            for (int ot = 0; ot < NOT; ++ot) {
+                const f4 a = ld4(wimg + ((size_t)(ot * NCH + c) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < NPT; ++i)
+                    if (t0 + 4 * i < ntiles) acc[i][ot] = mfma4(a, bop[i], acc[i][ot]);   // wave-uniform
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+            if (t0 + 4 * i < ntiles)
+#pragma unroll
+                for (int ot = 0; ot < NOT; ++ot) store(t0 + 4 * i, ot, acc[i][ot]);
+    }
+}
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+// w3img: [2][7][64][4] (24 -> 32 padded output channels), b3: 32; w4img: [3][14][64][4], b4: 48.
+__global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const float* __restrict__ w3img,
+                                                     const float* __restrict__ b3, const float* __restrict__ w4img,
+                                                     const float* __restrict__ b4, float* __restrict__ tokens, int L) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int per = cx.bands + cz.bands;
+    const int b = blockIdx.x / per;
+    int k = blockIdx.x - b * per;
+    const bool is_z = k >= cx.bands;
+    if (is_z) k -= cx.bands;
+    const float* __restrict__ in = is_z ? cz.in : cx.in;
+    const float* __restrict__ pos = is_z ? cz.pos : cx.pos;
+    const int S2 = is_z ? cz.S2 : cx.S2;
+    const int R4 = is_z ? cz.r4 : cx.r4;
+    const int tok_off = is_z ? cz.tok_off : cx.tok_off;
+    const int S3 = S2 >> 1, S4 = S2 >> 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, px = lane & 15;
+
+    // band geometry: token rows [y4_0, y4_0+R4) <- layer-3 rows [2*y4_0-1, ..] (2R4+1 rows)
+    //                                         <- layer-2 rows [4*y4_0-3, ..] (4R4+3 rows)
+    const int y4_0 = k * R4;
+    const int r3_0 = 2 * y4_0 - 1, NR3 = 2 * R4 + 1;
+    const int r2_0 = 2 * r3_0 - 1, NR2 = 2 * NR3 + 1;
+    const int pitch2 = S2 + 1, half2 = S2 >> 1, npix2 = stem_b_npix2(S2, R4);
+    const int pitch3 = S3 + 1, half3 = S3 >> 1, npix3 = stem_b_npix3(S2, R4);
+    f4* map2 = reinterpret_cast<f4*>(sm);          // 3 quads
+    f4* map3 = map2 + 3 * npix2;                   // 6 quads
+
+    for (int i = threadIdx.x; i < 3 * npix2 + 6 * npix3; i += 256) map2[i] = splat4(0.f);
+    __syncthreads();
+    // layer-2 activations of the band -> map2 (rows outside the image stay zero)
+    for (int i = threadIdx.x; i < NR2 * S2 * 3; i += 256) {
+        const int icq = i % 3, pc = i / 3;
+        const int lr = pc / S2, col = pc - lr * S2;
+        const int r2 = r2_0 + lr;
+        if (r2 >= 0 && r2 < S2) {
+            const f4 v = ld4(in + (((size_t)b * S2 + r2) * S2 + col) * 12 + 4 * icq);
+            map2[icq * npix2 + lr * pitch2 + ((col & 1) ? half2 + 1 + (col >> 1) : (col >> 1))] = v;
         }
     }
-    if constexpr (HSWISH) {
-#pragma unroll
-        for (int j = 0; j < OCG; ++j) acc[j] = hardswish(acc[j]);
+    __syncthreads();
+
+    // ---- layer 3 (12 -> 24, Hardswish): band rows r3_0 .. r3_0+NR3-1; rows outside the image stay 0
+    {
+        const int lr_first = r3_0 < 0 ? 1 : 0;                 // local layer-3 row 0 is the padding row at the top
+        const int nrows = NR3 - lr_first;
+        const int w3_log2 = ilog2(S3);
+        const int ntiles = (nrows * S3) >> 4;                  // S3 >= 8 and nrows*S3 is a multiple of 16 here
+        auto store3 = [&](int t, int ot, f4 v) {
+            if (16 * ot + 4 * q < 24) {
+                const int op = 16 * t + px;
+                const int y = op >> w3_log2, x = op - (y << w3_log2);
+                v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
+                map3[(4 * ot + q) * npix3 + (y + lr_first) * pitch3 + ((x & 1) ? half3 + 1 + (x >> 1) : (x >> 1))] = v;
+            }
+        };
+        // the first computed layer-3 row (local lr_first) reads layer-2 local rows 2*lr_first ..
+        conv_s2_mfma<3, 2, 4>(map2 + 2 * lr_first * pitch2, npix2, pitch2, half2, w3_log2, ntiles, w3img, b3, wave, lane,
+                              store3);
     }
-    float* dst;
-    if constexpr (TOKENS) {
-        const int t = py * Wo + qx;
-        const float* pp = pos + (size_t)t * COUT + g * OCG;
-#pragma unroll
-        for (int j = 0; j < OCG; ++j) acc[j] += pp[j];
-        dst = out + ((size_t)b * L + tok_off + t) * COUT + g * OCG;
-    } else {
-        dst = out + (size_t)idx * COUT + g * OCG;
-    }
-    if constexpr (OCG % 4 == 0) {
-#pragma unroll
-        for (int j = 0; j < OCG; j += 4) st4(dst + j, f4{acc[j], acc[j + 1], acc[j + 2], acc[j + 3]});
-    } else {
-#pragma unroll
-        for (int j = 0; j < OCG; j += 2) *reinterpret_cast<float2*>(dst + j) = float2{acc[j], acc[j + 1]};
+    __syncthreads();
+    // ---- layer 4 (24 -> 48) + pos-embed -> token rows -------------------------------------------
+    {
+        const int w4_log2 = ilog2(S4);
+        const int ntiles = (R4 * S4 + 15) >> 4;
+        const int npx = R4 * S4;
+        auto store4 = [&](int t, int ot, f4 v) {
+            const int op = 16 * t + px;
+            if (op < npx) {
+                const int tk = y4_0 * S4 + op;                 // token index inside this crop
+                const f4 pe = ld4(pos + (size_t)tk * 48 + 16 * ot + 4 * q);
+                st4(tokens + ((size_t)b * L + tok_off + tk) * 48 + 16 * ot + 4 * q, v + pe);
+            }
+        };
+        conv_s2_mfma<6, 3, 1>(map3, npix3, pitch3, half3, w4_log2, ntiles, w4img, b4, wave, lane, store4);
     }
 }
 
