@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -111,6 +112,17 @@ int fold_conv_bn(const TensorMap& tm, const std::string& conv, const std::string
     return VT_OK;
 }
 
+// [cout][cin][3][3] -> [r][cin][s][cout]: the scalar-weight sections of vt_stem.h (stem_a)
+std::vector<float> pack_conv_sections(const std::vector<double>& w, int cout, int cin) {
+    std::vector<float> out((size_t)cout * cin * 9);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < cin; ++c)
+            for (int s = 0; s < 3; ++s)
+                for (int j = 0; j < cout; ++j)
+                    out[(((size_t)r * cin + c) * 3 + s) * cout + j] = (float)w[((size_t)j * cin + c) * 9 + r * 3 + s];
+    return out;
+}
+
 // [cout][cin][3][3] -> [group][tap][cin][ocg]
 std::vector<float> pack_conv_groups(const std::vector<double>& w, int cout, int cin, int ocg) {
     std::vector<float> out((size_t)cout * cin * 9);
@@ -185,7 +197,19 @@ int check_ready(vt_model* m, int B) {
 // Band sizes per crop side.  stem_a: r2 layer-2 rows per workgroup (256 output pixels);
 // stem_b: r4 token rows per workgroup (LDS <= ~50 KB so three workgroups share a CU).
 struct StemPlan { int r2, r4; };
-StemPlan stem_plan(int T) {
+int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
+StemPlan stem_plan_default(int T);
+StemPlan stem_plan(int T) {   // VT_STEM_R2_<T> / VT_STEM_R4_<T> override the defaults (tuning aid)
+    StemPlan p = stem_plan_default(T);
+    const std::string t = std::to_string(T);
+    p.r2 = env_int(("VT_STEM_R2_" + t).c_str(), p.r2);
+    p.r4 = env_int(("VT_STEM_R4_" + t).c_str(), p.r4);
+    return p;
+}
+StemPlan stem_plan_default(int T) {
     switch (T) {
         case 64: return {16, 4};    // layer-2 map 16x16, tokens 4x4: one band each
         case 128: return {8, 4};    // 32x32 -> 4 bands; tokens 8x8 -> 2 bands
@@ -355,8 +379,8 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         const std::string p = "patch_embed.net." + std::to_string(2 * i);
         std::vector<double> w, b;
         if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
-        if (i < 2) {   // VALU layers: [tap][cin][cout], weights become scalar operands
-            if ((rc = upload(m->stem_w[i], pack_conv_groups(w, STEM_CH[i + 1], STEM_CH[i], STEM_CH[i + 1])))) return rc;
+        if (i < 2) {   // VALU layers: [r][cin][s][cout] sections, weights become scalar operands
+            if ((rc = upload(m->stem_w[i], pack_conv_sections(w, STEM_CH[i + 1], STEM_CH[i])))) return rc;
             if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
         } else {       // MFMA layers: A-operand images, bias padded to whole 16-channel tiles
             const int tiles = (STEM_CH[i + 1] + 15) / 16, nch = (9 * (STEM_CH[i] / 4) + 3) / 4;

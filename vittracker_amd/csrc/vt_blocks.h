@@ -110,26 +110,36 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
             if (T < NT) {
                 f4 h[NC];
                 layer_norm_img(x[i], h, P + O_LN1G, P + O_LN1B, q);
+                {   // q and k: 6 independent chains, rows = features, cols = tokens (B = h shared)
+                    f4 acc[2 * NC];
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) {        // q: rows = q features, cols = tokens
-                    f4 acc = ld4(P + O_BQKV + 16 * ot + 4 * q);
+                    for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(P + O_BQKV + 16 * ot + 4 * q);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(wimg(P + O_WQKV, ot * NC + c, lane), h[c], acc);
-                    qr[i][ot] = acc;
+                    for (int c = 0; c < NC; ++c) {
+                        f4 a[2 * NC];
+#pragma unroll
+                        for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = wimg(P + O_WQKV, ot * NC + c, lane);
+                        mfma4_shared_b(a, h[c], acc);
+                    }
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) {
+                        qr[i][ot] = acc[ot];
+                        Kimg[(T * NC + ot) * 64 + lane] = acc[NC + ot];
+                    }
                 }
+                {   // v, operands swapped: rows = tokens, cols = v features (A = h shared) -> V^T image
+                    f4 acc[NC];
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) {        // k
-                    f4 acc = ld4(P + O_BQKV + C + 16 * ot + 4 * q);
+                    for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(wimg(P + O_WQKV, (NC + ot) * NC + c, lane), h[c], acc);
-                    Kimg[(T * NC + ot) * 64 + lane] = acc;
-                }
+                    for (int c = 0; c < NC; ++c) {
+                        f4 bw[NC];
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) {        // v, operands swapped: rows = tokens, cols = v features
-                    f4 acc = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
+                        for (int ot = 0; ot < NC; ++ot) bw[ot] = wimg(P + O_WQKV, (2 * NC + ot) * NC + c, lane);
+                        mfma4_shared_a(h[c], bw, acc);
+                    }
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(h[c], wimg(P + O_WQKV, (2 * NC + ot) * NC + c, lane), acc);
-                    Vimg[(ot * NT + T) * 64 + lane] = acc;
+                    for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
                 }
             }
         }
@@ -141,14 +151,26 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
             if (T < NT) {
                 f4 s[NT];
                 float m = -3.0e38f;
+                constexpr int JG = 5;                    // key tiles per group = independent chains
+                static_assert(NT % JG == 0, "NT must be a multiple of 5");
 #pragma unroll
-                for (int J = 0; J < NT; ++J) {           // S^T tile: rows = keys of tile J, cols = queries
-                    f4 acc = splat4(0.f);
+                for (int j0 = 0; j0 < NT; j0 += JG) {    // S^T tiles: rows = keys, cols = queries (B = q shared)
+                    f4 acc[JG];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(Kimg[(J * NC + c) * 64 + lane], qr[i][c], acc);
-                    acc = acc * splat4(scale);           // (q @ k^T) * scale, attn.py:40
-                    s[J] = acc;
-                    m = fmaxf(m, hmax4(acc));
+                    for (int j = 0; j < JG; ++j) acc[j] = splat4(0.f);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        f4 a[JG];
+#pragma unroll
+                        for (int j = 0; j < JG; ++j) a[j] = Kimg[((j0 + j) * NC + c) * 64 + lane];
+                        mfma4_shared_b(a, qr[i][c], acc);
+                    }
+#pragma unroll
+                    for (int j = 0; j < JG; ++j) {
+                        acc[j] = acc[j] * splat4(scale);     // (q @ k^T) * scale, attn.py:40
+                        s[j0 + j] = acc[j];
+                        m = fmaxf(m, hmax4(acc[j]));
+                    }
                 }
                 m = quad_max(m);
                 float den = 0.f;
@@ -163,18 +185,24 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                 const float rden = 1.0f / quad_sum(den);
                 f4 o[NC];
 #pragma unroll
-                for (int t = 0; t < NC; ++t) {           // O^T = V^T P^T: rows = features, cols = queries
-                    f4 acc = splat4(0.f);
+                for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
 #pragma unroll
-                    for (int J = 0; J < NT; ++J) acc = mfma4(Vimg[(t * NT + J) * 64 + lane], s[J], acc);
-                    o[t] = acc * splat4(rden);
+                for (int J = 0; J < NT; ++J) {           // O^T = V^T P^T: 3 feature-tile chains share B = P_J
+                    f4 a[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J) * 64 + lane];
+                    mfma4_shared_b(a, s[J], o);
                 }
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) {
-                    f4 acc = x[i][ot] + ld4(P + O_BPROJ + 16 * ot + 4 * q);
+                for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(wimg(P + O_WPROJ, ot * NC + c, lane), o[c], acc);
-                    x[i][ot] = acc;
+                for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_BPROJ + 16 * ot + 4 * q);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    f4 a[NC];
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(P + O_WPROJ, ot * NC + c, lane);
+                    mfma4_shared_b(a, o[c], x[i]);
                 }
             }
         }
@@ -187,19 +215,31 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                 f4 h[NC];
                 layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
                 f4 hid[NH];
+                constexpr int HG = 6;                    // hidden tiles per group = independent chains
 #pragma unroll
-                for (int ot = 0; ot < NH; ++ot) {
-                    f4 acc = ld4(P + O_B1 + 16 * ot + 4 * q);
+                for (int g = 0; g < NH; g += HG) {
+                    f4 acc[HG];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc = mfma4(wimg(P + O_W1, ot * NC + c, lane), h[c], acc);
-                    hid[ot] = f4{gelu_erf(acc.x), gelu_erf(acc.y), gelu_erf(acc.z), gelu_erf(acc.w)};
+                    for (int j = 0; j < HG; ++j) acc[j] = ld4(P + O_B1 + 16 * (g + j) + 4 * q);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        f4 a[HG];
+#pragma unroll
+                        for (int j = 0; j < HG; ++j) a[j] = wimg(P + O_W1, (g + j) * NC + c, lane);
+                        mfma4_shared_b(a, h[c], acc);
+                    }
+#pragma unroll
+                    for (int j = 0; j < HG; ++j)
+                        hid[g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
                 }
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) {
-                    f4 acc = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
+                for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
 #pragma unroll
-                    for (int c = 0; c < NH; ++c) acc = mfma4(wimg(P + O_W2, ot * NH + c, lane), hid[c], acc);
-                    x[i][ot] = acc;
+                for (int c = 0; c < NH; ++c) {
+                    f4 a[NC];
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(P + O_W2, ot * NH + c, lane);
+                    mfma4_shared_b(a, hid[c], x[i]);
                 }
             }
         }

@@ -21,6 +21,25 @@ __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 acc) {
     return acc;
 }
 
+// N independent accumulator chains sharing the B operand (weights / keys as A): the four k-steps
+// are issued round-robin over the chains, so consecutive MFMAs never depend on each other
+// (v_mfma_f32_16x16x4_f32: 32-cycle issue but 40-cycle dependent-accumulator latency).
+template <int N>
+__device__ __forceinline__ void mfma4_shared_b(const f4 (&a)[N], f4 b, f4 (&acc)[N]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n][r], b[r], acc[n], 0, 0, 0);
+}
+// same with a shared A operand (activations as A: the transposed-output form used for V)
+template <int N>
+__device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)[N]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[n][r], acc[n], 0, 0, 0);
+}
+
 __device__ __forceinline__ f4 splat4(float v) { return f4{v, v, v, v}; }
 
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
@@ -41,9 +60,21 @@ __device__ __forceinline__ float quad_max(float v) {
 __device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hmax4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 exact, <= 5.5e-7 evaluated in fp32):
+// 1 rcp + 1 exp2 + 8 fma instead of the ~35-instruction libm erff; GELU error <= 5e-7 absolute.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+    return copysignf(fmaf(-(p * t), e, 1.0f), x);
+}
 __device__ __forceinline__ float gelu_erf(float u) {
     // nn.GELU() exact form: 0.5 u (1 + erf(u / sqrt 2))
-    return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
+    return 0.5f * u * (1.0f + erf_fast(u * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float hardswish(float y) {
     return y * fminf(fmaxf(y + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);

@@ -25,6 +25,17 @@
 
 namespace vts {
 
+// Makes a wave-uniform pointer opaque at this program point so loads through it cannot be hoisted
+// above it (hipcc otherwise hoists every loop-invariant scalar weight load out of the pixel loops,
+// runs out of SGPRs and spills them to VGPR lanes: one v_readlane per weight use).
+// The result points into the constant address space, so the loads stay scalar (s_load).
+typedef __attribute__((address_space(4))) const float* sptr;
+__device__ __forceinline__ sptr opaque(const float* p) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(v));
+    return (sptr)v;
+}
+
 struct CropA {            // one crop for stem_a
     const float* in;      // (B, 3, T, T) NCHW
     float* out;           // (B, T/4, T/4, 12) NHWC
@@ -36,9 +47,23 @@ struct CropA {            // one crop for stem_a
 // LDS floats stem_a needs for a crop of side T with r2 rows per band
 __host__ __device__ constexpr int stem_a_lds_floats(int T, int r2) { return 6 * (2 * r2 + 1) * (T / 2 + 1); }
 
-__global__ __launch_bounds__(256) void stem_a_kernel(CropA cx, CropA cz, const float* __restrict__ w1,
-                                                     const float* __restrict__ b1, const float* __restrict__ w2,
-                                                     const float* __restrict__ b2) {
+// Scalar weight sections.  Weights are packed [r][c][s][cout] so the 3*COUT weights a thread needs
+// for one (kernel row r, input channel c) are contiguous; a section is fetched with a few wide
+// s_loads into SGPRs, and the NEXT section is requested before the current one is consumed.
+template <int N>
+__device__ __forceinline__ void load_section(float (&w)[N], const float* base, int sec) {
+    const sptr p = opaque(base + sec * N);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = p[i];
+}
+
+#ifndef VT_STEM_A_WAVES_PER_SIMD
+#define VT_STEM_A_WAVES_PER_SIMD 5
+#endif
+
+__global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
+    CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
+    const float* __restrict__ w2g, const float* __restrict__ b2) {
     extern __shared__ __attribute__((aligned(16))) float l1[];   // [6][NR1][PITCH]
     const int per = cx.bands + cz.bands;
     const int b = blockIdx.x / per;
@@ -62,27 +87,42 @@ __global__ __launch_bounds__(256) void stem_a_kernel(CropA cx, CropA cz, const f
 #pragma unroll
             for (int j = 0; j < 6; ++j) a0[j] = a1[j] = 0.f;
         } else {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+            // all nine (row, channel) input fetches first: 9 x (16 B + 4 B) in flight per thread
+            f4 v[3][3];
+            float vm[3][3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int iy = 2 * p1 + r - 1;
-                if (iy < 0) continue;            // zero padding: the tap adds exactly 0
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float* row = in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp;
-                    const f4 v = ld4(row);
-                    const float vm = qp > 0 ? row[-1] : 0.f;
-                    const float t0[3] = {vm, v.x, v.y}, t1[3] = {v.y, v.z, v.w};
-#pragma unroll
-                    for (int s = 0; s < 3; ++s)
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            const float ww = w1[((r * 3 + s) * 3 + c) * 6 + j];
-                            a0[j] = fmaf(t0[s], ww, a0[j]);
-                            a1[j] = fmaf(t1[s], ww, a1[j]);
-                        }
+                    if (iy >= 0) {
+                        const float* row = in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp;
+                        v[r][c] = ld4(row);
+                        vm[r][c] = qp > 0 ? row[-1] : 0.f;
+                    } else {                     // zero padding above the image
+                        v[r][c] = splat4(0.f);
+                        vm[r][c] = 0.f;
+                    }
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+            float wa[18], wb[18];
+            load_section(wa, w1g, 0);
+#pragma unroll
+            for (int sec = 0; sec < 9; ++sec) {
+                float (&cur)[18] = (sec & 1) ? wb : wa;
+                float (&nxt)[18] = (sec & 1) ? wa : wb;
+                if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
+                const int r = sec / 3, c = sec % 3;
+                const float t0[3] = {vm[r][c], v[r][c].x, v[r][c].y}, t1[3] = {v[r][c].y, v[r][c].z, v[r][c].w};
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
+                        a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
+                    }
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]); a1[j] = hardswish(a1[j]); }
@@ -103,18 +143,20 @@ __global__ __launch_bounds__(256) void stem_a_kernel(CropA cx, CropA cz, const f
         float acc[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) acc[j] = b2[j];
+        float wa[36], wb[36];
+        load_section(wa, w2g, 0);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float* rowp = l1 + (2 * pl + r) * PITCH + q;
+        for (int sec = 0; sec < 18; ++sec) {
+            float (&cur)[36] = (sec & 1) ? wb : wa;
+            float (&nxt)[36] = (sec & 1) ? wa : wb;
+            if (sec + 1 < 18) load_section(nxt, w2g, sec + 1);
+            const int r = sec / 6, c = sec % 6;
+            const float* pc = l1 + c * plane + (2 * pl + r) * PITCH + q;
+            const float t[3] = {pc[HALF], pc[0], pc[HALF + 1]};   // columns 2q-1, 2q, 2q+1
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const float* pc = rowp + c * plane;
-                const float t[3] = {pc[HALF], pc[0], pc[HALF + 1]};   // columns 2q-1, 2q, 2q+1
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) acc[j] = fmaf(t[s], w2[((r * 3 + s) * 6 + c) * 12 + j], acc[j]);
-            }
+                for (int j = 0; j < 12; ++j) acc[j] = fmaf(t[s], cur[s * 12 + j], acc[j]);
         }
         float* dst = out + (((size_t)b * W2 + p0 + pl) * W2 + q) * 12;
 #pragma unroll
