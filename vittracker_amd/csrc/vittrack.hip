@@ -139,7 +139,7 @@ std::vector<float> pack_conv_groups(const std::vector<double>& w, int cout, int 
 // implicit GEMM of vt_head.h: element r of lane l of (ot, c) = w[oc = 16 ot + (l & 15)][ic = 4 icq + r][tap]
 // with quad Q = 4 c + (l >> 4), (tap, icq) = divmod(Q, cin / 4); zero beyond cout or 9 * cin / 4 quads.
 void pack_conv_image(const std::vector<double>& w, int cout, int cin, float* dst) {
-    const int nq = cin / 4, nqt = 9 * nq, nch = (nqt + 3) / 4, not_ = (cout + 15) / 16;
+    const int nq = (cin + 3) / 4, nqt = 9 * nq, nch = (nqt + 3) / 4, not_ = (cout + 15) / 16;   // cin padded to quads
     for (int ot = 0; ot < not_; ++ot)
         for (int c = 0; c < nch; ++c)
             for (int l = 0; l < 64; ++l)
@@ -148,7 +148,7 @@ void pack_conv_image(const std::vector<double>& w, int cout, int cin, float* dst
                     float v = 0.f;
                     if (oc < cout && Q < nqt) {
                         const int tap = Q / nq, ic = 4 * (Q % nq) + r;
-                        v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
+                        if (ic < cin) v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
                     }
                     dst[(((size_t)ot * nch + c) * 64 + l) * 4 + r] = v;
                 }
@@ -379,11 +379,11 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         const std::string p = "patch_embed.net." + std::to_string(2 * i);
         std::vector<double> w, b;
         if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
-        if (i < 2) {   // VALU layers: [r][cin][s][cout] sections, weights become scalar operands
+        if (i < 1) {   // VALU layer: [r][cin][s][cout] sections, weights become scalar operands
             if ((rc = upload(m->stem_w[i], pack_conv_sections(w, STEM_CH[i + 1], STEM_CH[i])))) return rc;
             if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
         } else {       // MFMA layers: A-operand images, bias padded to whole 16-channel tiles
-            const int tiles = (STEM_CH[i + 1] + 15) / 16, nch = (9 * (STEM_CH[i] / 4) + 3) / 4;
+            const int tiles = (STEM_CH[i + 1] + 15) / 16, nch = (9 * ((STEM_CH[i] + 3) / 4) + 3) / 4;
             std::vector<float> img((size_t)tiles * nch * 256), bias((size_t)tiles * 16, 0.f);
             pack_conv_image(w, STEM_CH[i + 1], STEM_CH[i], img.data());
             for (int o = 0; o < STEM_CH[i + 1]; ++o) bias[o] = (float)b[o];

@@ -144,11 +144,15 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
             }
         }
         __syncthreads();
+        // In the last block the template rows only matter as keys / values: their attention
+        // output, proj and MLP never reach the head (vit_dist.py:126 keeps the search rows only),
+        // so those tiles stop after publishing K / V -- unless the caller asked for the residual.
+        const bool last_skip_z = (blk == depth_total - 1) && (resid == nullptr);
         // ---- attention + proj (residual add) --------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT) {
+            if (T < NT && !(last_skip_z && 16 * T < len_z)) {
                 f4 s[NT];
                 float m = -3.0e38f;
                 constexpr int JG = 5;                    // key tiles per group = independent chains
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT) {
+            if (T < NT && !(last_skip_z && 16 * T < len_z)) {
                 f4 h[NC];
                 layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
                 f4 hid[NH];

@@ -36,153 +36,7 @@ __device__ __forceinline__ sptr opaque(const float* p) {
     return (sptr)v;
 }
 
-struct CropA {            // one crop for stem_a
-    const float* in;      // (B, 3, T, T) NCHW
-    float* out;           // (B, T/4, T/4, 12) NHWC
-    int T;                // crop side
-    int r2;               // layer-2 rows per band
-    int bands;            // (T/4) / r2
-};
-
-// LDS floats stem_a needs for a crop of side T with r2 rows per band
-__host__ __device__ constexpr int stem_a_lds_floats(int T, int r2) { return 6 * (2 * r2 + 1) * (T / 2 + 1); }
-
-// Scalar weight sections.  Weights are packed [r][c][s][cout] so the 3*COUT weights a thread needs
-// for one (kernel row r, input channel c) are contiguous; a section is fetched with a few wide
-// s_loads into SGPRs, and the NEXT section is requested before the current one is consumed.
-template <int N>
-__device__ __forceinline__ void load_section(float (&w)[N], const float* base, int sec) {
-    const sptr p = opaque(base + sec * N);
-#pragma unroll
-    for (int i = 0; i < N; ++i) w[i] = p[i];
-}
-
-#ifndef VT_STEM_A_WAVES_PER_SIMD
-#define VT_STEM_A_WAVES_PER_SIMD 5
-#endif
-
-__global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
-    CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
-    const float* __restrict__ w2g, const float* __restrict__ b2) {
-    extern __shared__ __attribute__((aligned(16))) float l1[];   // [6][NR1][PITCH]
-    const int per = cx.bands + cz.bands;
-    const int b = blockIdx.x / per;
-    int k = blockIdx.x - b * per;
-    const bool is_z = k >= cx.bands;
-    if (is_z) k -= cx.bands;
-    const float* __restrict__ in = is_z ? cz.in : cx.in;
-    float* __restrict__ out = is_z ? cz.out : cx.out;
-    const int T = is_z ? cz.T : cx.T;
-    const int R2 = is_z ? cz.r2 : cx.r2;
-    const int W1 = T >> 1, HALF = T >> 2, PITCH = W1 + 1, NR1 = 2 * R2 + 1, W2 = T >> 2;
-    const int p0 = k * R2;                       // first layer-2 row of this band
-    const int plane = NR1 * PITCH;
-
-    // ---- layer 1: rows 2*p0-1 .. 2*p0+2*R2-1 of the layer-1 map, two pixels per thread ----------
-    for (int i = threadIdx.x; i < NR1 * HALF; i += 256) {
-        const int lr = i / HALF, qp = i - lr * HALF;
-        const int p1 = 2 * p0 - 1 + lr;
-        float a0[6], a1[6];
-        if (p1 < 0) {                            // row -1 of the layer-1 map = layer 2's zero padding
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = 0.f;
-        } else {
-            // all nine (row, channel) input fetches first: 9 x (16 B + 4 B) in flight per thread
-            f4 v[3][3];
-            float vm[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int iy = 2 * p1 + r - 1;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (iy >= 0) {
-                        const float* row = in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp;
-                        v[r][c] = ld4(row);
-                        vm[r][c] = qp > 0 ? row[-1] : 0.f;
-                    } else {                     // zero padding above the image
-                        v[r][c] = splat4(0.f);
-                        vm[r][c] = 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
-            float wa[18], wb[18];
-            load_section(wa, w1g, 0);
-#pragma unroll
-            for (int sec = 0; sec < 9; ++sec) {
-                float (&cur)[18] = (sec & 1) ? wb : wa;
-                float (&nxt)[18] = (sec & 1) ? wa : wb;
-                if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
-                const int r = sec / 3, c = sec % 3;
-                const float t0[3] = {vm[r][c], v[r][c].x, v[r][c].y}, t1[3] = {v[r][c].y, v[r][c].z, v[r][c].w};
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
-                        a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
-                    }
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]); a1[j] = hardswish(a1[j]); }
-        }
-        float* dst = l1 + lr * PITCH;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            dst[j * plane + qp] = a0[j];                 // even column 2*qp
-            dst[j * plane + HALF + 1 + qp] = a1[j];      // odd column 2*qp+1
-        }
-    }
-    for (int i = threadIdx.x; i < 6 * NR1; i += 256) l1[i * PITCH + HALF] = 0.f;   // column -1
-    __syncthreads();
-
-    // ---- layer 2: one output pixel x 12 channels per thread ------------------------------------
-    for (int i = threadIdx.x; i < R2 * W2; i += 256) {
-        const int pl = i / W2, q = i - pl * W2;
-        float acc[12];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) acc[j] = b2[j];
-        float wa[36], wb[36];
-        load_section(wa, w2g, 0);
-#pragma unroll
-        for (int sec = 0; sec < 18; ++sec) {
-            float (&cur)[36] = (sec & 1) ? wb : wa;
-            float (&nxt)[36] = (sec & 1) ? wa : wb;
-            if (sec + 1 < 18) load_section(nxt, w2g, sec + 1);
-            const int r = sec / 6, c = sec % 6;
-            const float* pc = l1 + c * plane + (2 * pl + r) * PITCH + q;
-            const float t[3] = {pc[HALF], pc[0], pc[HALF + 1]};   // columns 2q-1, 2q, 2q+1
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int j = 0; j < 12; ++j) acc[j] = fmaf(t[s], cur[s * 12 + j], acc[j]);
-        }
-        float* dst = out + (((size_t)b * W2 + p0 + pl) * W2 + q) * 12;
-#pragma unroll
-        for (int j = 0; j < 12; j += 4)
-            st4(dst + j, f4{hardswish(acc[j]), hardswish(acc[j + 1]), hardswish(acc[j + 2]), hardswish(acc[j + 3])});
-    }
-}
-
-// ------------------------------------------------------------------------------------------ stem_b
-struct CropB {
-    const float* in;      // (B, S2, S2, 12) NHWC, S2 = T/4
-    const float* pos;     // (S4*S4, 48)
-    int S2;               // layer-2 map side
-    int r4;               // token rows per band
-    int bands;            // (S2/4) / r4
-    int tok_off;          // first token row of this crop in the (B, L, 48) matrix
-};
-
 constexpr int round16(int v) { return (v + 15) & ~15; }
-// plane sizes (pixels) of the two LDS maps for a band of r4 token rows of a crop with S2
-__host__ __device__ constexpr int stem_b_npix2(int S2, int r4) { return round16((4 * r4 + 3) * (S2 + 1)); }
-__host__ __device__ constexpr int stem_b_npix3(int S2, int r4) { return round16((2 * r4 + 1) * (S2 / 2 + 1)); }
-__host__ __device__ constexpr int stem_b_lds_bytes(int S2, int r4) {
-    return (3 * stem_b_npix2(S2, r4) + 6 * stem_b_npix3(S2, r4)) * 16;
-}
-
 constexpr int nchunks_q(int nq) { return (9 * nq + 3) / 4; }
 
 // Implicit-GEMM stride-2 3x3 conv over a parity-split quad-planar LDS map.
@@ -240,6 +94,160 @@ __device__ __forceinline__ void conv_s2_mfma(const f4* in_map, int npix_in, int 
 }
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+
+struct CropA {            // one crop for stem_a
+    const float* in;      // (B, 3, T, T) NCHW
+    float* out;           // (B, T/4, T/4, 12) NHWC
+    int T;                // crop side
+    int r2;               // layer-2 rows per band
+    int bands;            // (T/4) / r2
+};
+
+// LDS floats stem_a needs for a crop of side T with r2 rows per band
+// (two quad planes: layer-1 channels 0-3 and 4-5 + zero padding; plane = rows x (even | -1 | odd) columns)
+__host__ __device__ constexpr int stem_a_npix1(int T, int r2) { return round16((2 * r2 + 1) * (T / 2 + 1)); }
+__host__ __device__ constexpr int stem_a_lds_floats(int T, int r2) { return 2 * stem_a_npix1(T, r2) * 4; }
+
+// Scalar weight sections.  Weights are packed [r][c][s][cout] so the 3*COUT weights a thread needs
+// for one (kernel row r, input channel c) are contiguous; a section is fetched with a few wide
+// s_loads into SGPRs, and the NEXT section is requested before the current one is consumed.
+template <int N>
+__device__ __forceinline__ void load_section(float (&w)[N], const float* base, int sec) {
+    const sptr p = opaque(base + sec * N);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = p[i];
+}
+
+#ifndef VT_STEM_A_WAVES_PER_SIMD
+#define VT_STEM_A_WAVES_PER_SIMD 4
+#endif
+
+// w1g: [r][c][s][6] scalar sections (layer 1, VALU); w2img: [1][5][64][4] MFMA image of layer 2 with
+// the input channels padded 6 -> 8; b2: 16 (12 used).
+__global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
+    CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
+    const float* __restrict__ w2img, const float* __restrict__ b2) {
+    extern __shared__ __attribute__((aligned(16))) float lds_a[];
+    f4* map1 = reinterpret_cast<f4*>(lds_a);     // [2 quads][NR1 rows][PITCH]: layer-1 output
+    const int per = cx.bands + cz.bands;
+    const int b = blockIdx.x / per;
+    int k = blockIdx.x - b * per;
+    const bool is_z = k >= cx.bands;
+    if (is_z) k -= cx.bands;
+    const float* __restrict__ in = is_z ? cz.in : cx.in;
+    float* __restrict__ out = is_z ? cz.out : cx.out;
+    const int T = is_z ? cz.T : cx.T;
+    const int R2 = is_z ? cz.r2 : cx.r2;
+    const int W1 = T >> 1, HALF = T >> 2, PITCH = W1 + 1, NR1 = 2 * R2 + 1, W2 = T >> 2;
+    const int p0 = k * R2;                       // first layer-2 row of this band
+    const int npix1 = stem_a_npix1(T, R2);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- layer 1 (3 -> 6, VALU): rows 2*p0-1 .. 2*p0+2*R2-1 of the layer-1 map, two pixels per
+    // thread, software-pipelined over passes of 256 pixel pairs: the nine 16-byte row fetches of the
+    // next pass are in flight while the current pass is computed.
+    const int npairs = NR1 * HALF;
+    auto fetch = [&](int i, f4 (&v)[3][3]) {
+        i = i < npairs ? i : npairs - 1;            // clamped lanes recompute the last pair
+        const int lr = i / HALF, qp = i - lr * HALF;
+        const int p1 = 2 * p0 - 1 + lr;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int iy = 2 * p1 + r - 1;                // < 0 only for r = 0 at the image top (and for
+            const float keep = iy >= 0 ? 1.f : 0.f; // the padding row p1 = -1): branch-free zeroing
+            iy = iy >= 0 ? iy : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[r][c] = ld4(in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp) * splat4(keep);
+        }
+    };
+    auto compute = [&](int i, const f4 (&v)[3][3]) {
+        const bool in_range = i < npairs;           // clamped lanes compute (keeps shuffles whole) but do not store
+        i = in_range ? i : npairs - 1;
+        const int lr = i / HALF, qp = i - lr * HALF;
+        const int p1 = 2 * p0 - 1 + lr;
+        float a0[6], a1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+        float wa[18], wb[18];
+        load_section(wa, w1g, 0);
+#pragma unroll
+        for (int sec = 0; sec < 9; ++sec) {
+            float (&cur)[18] = (sec & 1) ? wb : wa;
+            float (&nxt)[18] = (sec & 1) ? wa : wb;
+            if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
+            const int r = sec / 3, c = sec % 3;
+            // column 4*qp-1 is the previous lane's .w (same image row); 0 left of the image
+            const float left = __shfl_up(v[r][c].w, 1, 64);
+            const float t0[3] = {qp > 0 ? left : 0.f, v[r][c].x, v[r][c].y}, t1[3] = {v[r][c].y, v[r][c].z, v[r][c].w};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
+                    a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
+                }
+        }
+        const float live = p1 < 0 ? 0.f : 1.f;      // row -1 of the layer-1 map = layer 2's zero padding
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]) * live; a1[j] = hardswish(a1[j]) * live; }
+        if (in_range) {
+            f4* dst = map1 + lr * PITCH;
+            dst[qp] = f4{a0[0], a0[1], a0[2], a0[3]};                   // even column 2*qp, channels 0-3
+            dst[npix1 + qp] = f4{a0[4], a0[5], 0.f, 0.f};               //                   channels 4-5 (+ padding)
+            dst[HALF + 1 + qp] = f4{a1[0], a1[1], a1[2], a1[3]};        // odd column 2*qp+1
+            dst[npix1 + HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
+        }
+    };
+    {
+        f4 va[3][3], vb[3][3];
+        fetch(threadIdx.x, va);
+        for (int base = 0; base + (int)(threadIdx.x & ~63) < npairs; base += 256) {   // whole waves drop out
+            const int i = base + threadIdx.x;
+            if (base + 256 + (int)(threadIdx.x & ~63) < npairs) fetch(i + 256, vb);   // next pass in flight
+            compute(i, va);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) va[r][c] = vb[r][c];
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * NR1; i += 256)                     // column -1 of every row
+        map1[(i / NR1) * npix1 + (i % NR1) * PITCH + HALF] = splat4(0.f);
+    __syncthreads();
+
+    // ---- layer 2 (6 -> 12, MFMA implicit GEMM) -> NHWC(12) in global memory -----------------------
+    const int w2_log2 = ilog2(W2);
+    const int q = lane >> 4, px = lane & 15;
+    auto store2 = [&](int t, int ot, f4 v) {
+        (void)ot;
+        if (q < 3) {
+            const int op = 16 * t + px;
+            const int y = op >> w2_log2, x = op - (y << w2_log2);
+            v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
+            st4(out + (((size_t)b * W2 + p0 + y) * W2 + x) * 12 + 4 * q, v);
+        }
+    };
+    conv_s2_mfma<2, 1, 4>(map1, npix1, PITCH, HALF, w2_log2, (R2 * W2) >> 4, w2img, b2, wave, lane, store2);
+}
+
+// ------------------------------------------------------------------------------------------ stem_b
+struct CropB {
+    const float* in;      // (B, S2, S2, 12) NHWC, S2 = T/4
+    const float* pos;     // (S4*S4, 48)
+    int S2;               // layer-2 map side
+    int r4;               // token rows per band
+    int bands;            // (S2/4) / r4
+    int tok_off;          // first token row of this crop in the (B, L, 48) matrix
+};
+
+// plane sizes (pixels) of the two LDS maps for a band of r4 token rows of a crop with S2
+__host__ __device__ constexpr int stem_b_npix2(int S2, int r4) { return round16((4 * r4 + 3) * (S2 + 1)); }
+__host__ __device__ constexpr int stem_b_npix3(int S2, int r4) { return round16((2 * r4 + 1) * (S2 / 2 + 1)); }
+__host__ __device__ constexpr int stem_b_lds_bytes(int S2, int r4) {
+    return (3 * stem_b_npix2(S2, r4) + 6 * stem_b_npix3(S2, r4)) * 16;
+}
 
 // w3img: [2][7][64][4] (24 -> 32 padded output channels), b3: 32; w4img: [3][14][64][4], b4: 48.
 __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const float* __restrict__ w3img,
