@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vt_blocks.h"
@@ -221,16 +222,24 @@ StemPlan stem_plan_default(int T) {
 int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens) {
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     const StemPlan px = stem_plan(Tx), pz = stem_plan(Tz);
+    for (const auto& pr : {std::make_pair(Tx, px), std::make_pair(Tz, pz)}) {
+        const int T = pr.first, r2 = pr.second.r2, r4 = pr.second.r4;
+        const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
+        if (r2 < 1 || r4 < 1 || (T / 4) % r2 || (T / 16) % r4 || (r2 * (T / 4)) % 256 || !(nt4 == 1 || nt4 == 2 || nt4 == 4) ||
+            (r4 * (T / 16)) % 16 || (((2 * r4 + 1) * (T / 8)) % 16 && ((2 * r4) * (T / 8)) % 16) ||
+            3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64)
+            return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
+    }
     vts::CropA ax{x, m->act_x.p, Tx, px.r2, (Tx / 4) / px.r2}, az{z, m->act_z.p, Tz, pz.r2, (Tz / 4) / pz.r2};
     const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
     hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
-                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p);
+                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, env_int("VT_SKIP_STEM_A", 0));
     HIP_TRY(hipGetLastError());
     vts::CropB bx{m->act_x.p, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
     vts::CropB bz{m->act_z.p, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
     const size_t lds_b = std::max(vts::stem_b_lds_bytes(Tx / 4, px.r4), vts::stem_b_lds_bytes(Tz / 4, pz.r4));
     hipLaunchKernelGGL(vts::stem_b_kernel, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
-                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L);
+                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, env_int("VT_SKIP_STEM_B", 0));
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -269,10 +278,10 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* conf = (o && o->conf) ? o->conf : m->conf.p;
     if (m->F == 8) {
         hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
-                           feat, m->head.p, score, size, offset);
+                           feat, m->head.p, score, size, offset, env_int("VT_SKIP_HEAD", 0));
     } else if (m->F == 16) {
         hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::Geo<16>::LDS_BYTES,
-                           st, feat, m->head.p, score, size, offset);
+                           st, feat, m->head.p, score, size, offset, env_int("VT_SKIP_HEAD", 0));
     } else {
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
     }

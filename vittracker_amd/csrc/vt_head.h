@@ -17,6 +17,7 @@
 // (tools/lds_conflicts.py).
 #pragma once
 #include "vt_common.h"
+#include "vt_conv.h"
 
 namespace vth {
 
@@ -58,12 +59,13 @@ struct Geo {
     }
 };
 
-// One 3x3 stride-1 conv + bias + ReLU between two LDS maps on MFMA.
+// One 3x3 stride-1 conv + bias + ReLU between two LDS maps on MFMA (core: vt_conv.h).
 template <int CIN, int COUT, int F>
 __device__ __forceinline__ void conv3x3_relu_mfma(const f4* in_map, f4* out_map, const float* __restrict__ wimg,
                                                   const float* __restrict__ bias, int wave, int lane) {
     using G = Geo<F>;
-    constexpr int NQ = CIN / 4, NQT = 9 * NQ, NCH = nchunks(CIN), NOT = ntiles(COUT), NPT = G::NPT;
+    constexpr int NQ = CIN / 4, NCH = nchunks(CIN), NOT = ntiles(COUT), NPT = G::NPT;
+    constexpr int MAXC = NOT == 1 ? (NCH <= 9 ? NCH : 9) : 7;       // <= 56-72 VGPRs of weights per pass
     const int q = lane >> 4;
     int base[NPT];
 #pragma unroll
@@ -75,23 +77,13 @@ __device__ __forceinline__ void conv3x3_relu_mfma(const f4* in_map, f4* out_map,
 #pragma unroll
         for (int i = 0; i < NPT; ++i) acc[i][ot] = bv;
     }
-#pragma unroll 3
-    for (int c = 0; c < NCH; ++c) {
-        int Q = 4 * c + q;
-        Q = Q < NQT ? Q : NQT - 1;          // pad quads: weights are zero, any finite B will do
-        const int tap = Q / NQ, icq = Q - tap * NQ;
+    auto off = [&](int c) {
+        int tap, icq;
+        vtc::decode_quad<NQ>(4 * c + q, tap, icq);
         const int dy = tap / 3, dx = tap - 3 * dy;
-        const int off = icq * G::NPIX + dy * G::P + dx;
-        f4 bop[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) bop[i] = in_map[off + base[i]];
-#pragma unroll
-        for (int ot = 0; ot < NOT; ++ot) {
-            const f4 a = ld4(wimg + ((size_t)(ot * NCH + c) * 64 + lane) * 4);
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) acc[i][ot] = mfma4(a, bop[i], acc[i][ot]);
-        }
-    }
+        return icq * G::NPIX + dy * G::P + dx;
+    };
+    vtc::conv_all_chunks<NOT, NPT, MAXC, NCH>(in_map, base, wimg, lane, off, acc);
 #pragma unroll
     for (int ot = 0; ot < NOT; ++ot) {
         if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
@@ -110,7 +102,7 @@ template <int F>
 __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ hw,
                                                           float* __restrict__ score, float* __restrict__ size,
-                                                          float* __restrict__ offset) {
+                                                          float* __restrict__ offset, int skip) {   // skip: diagnostic
     using G = Geo<F>;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     f4* in_map = reinterpret_cast<f4*>(sm);            // 12 quads
@@ -121,22 +113,24 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
 
-    for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += 256) in_map[i] = splat4(0.f);
+    if (!(skip & 1))
+        for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += 256) in_map[i] = splat4(0.f);
     __syncthreads();
     // (B,HW,C) tokens -> quad planes: map[c/4][p][q] = feat[b][p*F+q][c..c+3]   (vit_dist.py:126-129)
+    if (!(skip & 2))
     for (int i = threadIdx.x; i < F * F * (C / 4); i += 256) {
         const int icq = i / (F * F), pix = i % (F * F);
         in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] =
             ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
     }
     __syncthreads();
-    conv3x3_relu_mfma<C, W1, F>(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
+    if (!(skip & 4)) conv3x3_relu_mfma<C, W1, F>(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
     __syncthreads();
-    conv3x3_relu_mfma<W1, 16, F>(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
+    if (!(skip & 8)) conv3x3_relu_mfma<W1, 16, F>(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
     __syncthreads();
-    conv3x3_relu_mfma<16, 8, F>(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
+    if (!(skip & 16)) conv3x3_relu_mfma<16, 8, F>(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
     __syncthreads();
-    conv3x3_relu_mfma<8, 4, F>(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
+    if (!(skip & 16)) conv3x3_relu_mfma<8, 4, F>(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
     __syncthreads();
     // 1x1 conv + activation (head.py:187,194,200-201)
     for (int pix = threadIdx.x; pix < F * F; pix += 256) {

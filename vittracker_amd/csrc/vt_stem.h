@@ -21,7 +21,10 @@
 //          operand of a k-chunk is one ds_read_b128.  Layer 3's result tile is written straight
 //          into layer 4's input map; layer 4 adds the pos-embed and stores token rows.
 #pragma once
+#include <type_traits>
+
 #include "vt_common.h"
+#include "vt_conv.h"
 
 namespace vts {
 
@@ -37,60 +40,16 @@ __device__ __forceinline__ sptr opaque(const float* p) {
 }
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
-constexpr int nchunks_q(int nq) { return (9 * nq + 3) / 4; }
-
-// Implicit-GEMM stride-2 3x3 conv over a parity-split quad-planar LDS map.
+// Stride-2 3x3 conv over a parity-split quad-planar LDS map (core: vt_conv.h).
 //   in_map[icq * npix_in + row * pitch_in + (col odd ? half_in + 1 + col/2 : col/2)], local row 0
 //   = the row above the band's first needed row (zero row at the image top), entry half_in = col -1.
-// Output pixels are numbered row-major over (rows_out x wout); tile t = pixels 16t .. 16t+15.
-// Each wave takes tiles wave, wave+4, ... in groups of NPT; store(t_index_in_group, tile, ot, value).
-template <int NQ, int NOT, int NPT, typename Store>
-__device__ __forceinline__ void conv_s2_mfma(const f4* in_map, int npix_in, int pitch_in, int half_in, int wout_log2,
-                                             int ntiles, const float* __restrict__ wimg,
-                                             const float* __restrict__ bias, int wave, int lane, Store store) {
-    constexpr int NQT = 9 * NQ, NCH = nchunks_q(NQ);
-    const int q = lane >> 4, px = lane & 15;
-    for (int t0 = wave; t0 < ntiles; t0 += 4 * NPT) {
-        int base[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            int t = t0 + 4 * i;
-            t = t < ntiles ? t : ntiles - 1;             // clamped tiles are computed but not stored
-            const int op = 16 * t + px;
-            const int y = op >> wout_log2, x = op - (y << wout_log2);
-            base[i] = 2 * y * pitch_in + x;
-        }
-        f4 acc[NPT][NOT];
-#pragma unroll
-        for (int ot = 0; ot < NOT; ++ot) {
-            const f4 bv = ld4(bias + 16 * ot + 4 * q);
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) acc[i][ot] = bv;
-        }
-#pragma unroll 2
-        for (int c = 0; c < NCH; ++c) {
-            int Q = 4 * c + q;
-            Q = Q < NQT ? Q : NQT - 1;
-            const int tap = Q / NQ, icq = Q - tap * NQ;
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            const int off = icq * npix_in + dy * pitch_in + (dx == 1 ? 0 : (dx == 0 ? half_in : half_in + 1));
-            f4 bop[NPT];
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) bop[i] = in_map[off + base[i]];
-#pragma unroll
-            for (int ot = 0; ot < NOT; ++ot) {
-                const f4 a = ld4(wimg + ((size_t)(ot * NCH + c) * 64 + lane) * 4);
-#pragma unroll
-                for (int i = 0; i < NPT; ++i)
-                    if (t0 + 4 * i < ntiles) acc[i][ot] = mfma4(a, bop[i], acc[i][ot]);   // wave-uniform
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NPT; ++i)
-            if (t0 + 4 * i < ntiles)
-#pragma unroll
-                for (int ot = 0; ot < NOT; ++ot) store(t0 + 4 * i, ot, acc[i][ot]);
-    }
+// Per-lane map offset of this lane's quad of chunk c for a layer with NQ channel-quads per tap.
+template <int NQ>
+__device__ __forceinline__ int s2_chunk_off(int c, int q, int npix_in, int pitch_in, int half_in) {
+    int tap, icq;
+    vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+    const int dy = tap / 3, dx = tap - 3 * dy;
+    return icq * npix_in + dy * pitch_in + (dx == 1 ? 0 : (dx == 0 ? half_in : half_in + 1));
 }
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
@@ -126,7 +85,7 @@ __device__ __forceinline__ void load_section(float (&w)[N], const float* base, i
 // the input channels padded 6 -> 8; b2: 16 (12 used).
 __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
     CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
-    const float* __restrict__ w2img, const float* __restrict__ b2) {
+    const float* __restrict__ w2img, const float* __restrict__ b2, int skip) {   // skip: phase-timing diagnostic, 0 in production
     extern __shared__ __attribute__((aligned(16))) float lds_a[];
     f4* map1 = reinterpret_cast<f4*>(lds_a);     // [2 quads][NR1 rows][PITCH]: layer-1 output
     const int per = cx.bands + cz.bands;
@@ -143,7 +102,6 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
     const int npix1 = stem_a_npix1(T, R2);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
     // ---- layer 1 (3 -> 6, VALU): rows 2*p0-1 .. 2*p0+2*R2-1 of the layer-1 map, two pixels per
     // thread, software-pipelined over passes of 256 pixel pairs: the nine 16-byte row fetches of the
     // next pass are in flight while the current pass is computed.
@@ -200,7 +158,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
             dst[npix1 + HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
         }
     };
-    {
+    if (!(skip & 1)) {
         f4 va[3][3], vb[3][3];
         fetch(threadIdx.x, va);
         for (int base = 0; base + (int)(threadIdx.x & ~63) < npairs; base += 256) {   // whole waves drop out
@@ -213,6 +171,8 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
                 for (int c = 0; c < 3; ++c) va[r][c] = vb[r][c];
         }
     }
+    f4 w2a[5][1];                                // layer-2 weights: in flight across the barrier below
+    vtc::load_weights<1, 5, 5>(w2img, 0, 5, lane, w2a);
     for (int i = threadIdx.x; i < 2 * NR1; i += 256)                     // column -1 of every row
         map1[(i / NR1) * npix1 + (i % NR1) * PITCH + HALF] = splat4(0.f);
     __syncthreads();
@@ -229,7 +189,26 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
             st4(out + (((size_t)b * W2 + p0 + y) * W2 + x) * 12 + 4 * q, v);
         }
     };
-    conv_s2_mfma<2, 1, 4>(map1, npix1, PITCH, HALF, w2_log2, (R2 * W2) >> 4, w2img, b2, wave, lane, store2);
+    if (!(skip & 2)) {
+        const int ntiles = (R2 * W2) >> 4;
+        auto off2 = [&](int c) { return s2_chunk_off<2>(c, q, npix1, PITCH, HALF); };
+        for (int t0 = wave; t0 < ntiles; t0 += 16) {      // ntiles is a multiple of 16 (host check)
+            int base[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int op = 16 * (t0 + 4 * i) + px;
+                const int y = op >> w2_log2, x = op - (y << w2_log2);
+                base[i] = 2 * y * PITCH + x;
+            }
+            f4 acc[4][1];
+            const f4 bv = ld4(b2 + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][0] = bv;
+            vtc::mma_pass<1, 4, 5, 5>(map1, base, w2a, 0, off2, acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store2(t0 + 4 * i, 0, acc[i][0]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ stem_b
@@ -252,7 +231,8 @@ __host__ __device__ constexpr int stem_b_lds_bytes(int S2, int r4) {
 // w3img: [2][7][64][4] (24 -> 32 padded output channels), b3: 32; w4img: [3][14][64][4], b4: 48.
 __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const float* __restrict__ w3img,
                                                      const float* __restrict__ b3, const float* __restrict__ w4img,
-                                                     const float* __restrict__ b4, float* __restrict__ tokens, int L) {
+                                                     const float* __restrict__ b4, float* __restrict__ tokens, int L,
+                                                     int skip) {   // skip: phase-timing diagnostic, 0 in production
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int per = cx.bands + cz.bands;
     const int b = blockIdx.x / per;
@@ -279,9 +259,22 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
     f4* map2 = reinterpret_cast<f4*>(sm);          // 3 quads
     f4* map3 = map2 + 3 * npix2;                   // 6 quads
 
-    for (int i = threadIdx.x; i < 3 * npix2 + 6 * npix3; i += 256) map2[i] = splat4(0.f);
+    // Work split that keeps the waves on DIFFERENT weights (each weight tile crosses the 64 B/clk
+    // L1 fill path twice per workgroup instead of four times):
+    //   layer 3: wave = (output tile ot3 = wave & 1, pixel tiles of parity wave >> 1), all 7 chunks;
+    //   layer 4: wave = k-quarter of the 14 chunks for both pixel tiles and all 3 output tiles,
+    //            partial sums reduced through LDS.
+    // Both weight bursts are requested before the data they multiply exists.
+    constexpr int NCH3 = 7, NCH4 = 14;
+    const int ot3 = wave & 1, th3 = wave >> 1;
+    f4 w3a[NCH3][1];
+    vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a);
+
+    if (!(skip & 1))
+        for (int i = threadIdx.x; i < 3 * npix2 + 6 * npix3; i += 256) map2[i] = splat4(0.f);
     __syncthreads();
     // layer-2 activations of the band -> map2 (rows outside the image stay zero)
+    if (!(skip & 2))
     for (int i = threadIdx.x; i < NR2 * S2 * 3; i += 256) {
         const int icq = i % 3, pc = i / 3;
         const int lr = pc / S2, col = pc - lr * S2;
@@ -291,41 +284,108 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
             map2[icq * npix2 + lr * pitch2 + ((col & 1) ? half2 + 1 + (col >> 1) : (col >> 1))] = v;
         }
     }
+    const int c4_0 = (NCH4 * wave) >> 2, c4_n = ((NCH4 * (wave + 1)) >> 2) - c4_0;     // 3, 4, 3, 4 chunks
+    f4 w4a[4][3];
+    vtc::load_weights<3, 4, NCH4>(w4img, c4_0, c4_n, lane, w4a);
     __syncthreads();
 
     // ---- layer 3 (12 -> 24, Hardswish): band rows r3_0 .. r3_0+NR3-1; rows outside the image stay 0
-    {
+    if (!(skip & 4)) {
         const int lr_first = r3_0 < 0 ? 1 : 0;                 // local layer-3 row 0 is the padding row at the top
         const int nrows = NR3 - lr_first;
         const int w3_log2 = ilog2(S3);
-        const int ntiles = (nrows * S3) >> 4;                  // S3 >= 8 and nrows*S3 is a multiple of 16 here
-        auto store3 = [&](int t, int ot, f4 v) {
-            if (16 * ot + 4 * q < 24) {
-                const int op = 16 * t + px;
+        const int ntiles = (nrows * S3) >> 4;                  // <= 10 (checked on the host)
+        const f4* in3 = map2 + 2 * lr_first * pitch2;          // first computed row reads layer-2 local rows 2*lr_first..
+        auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, npix2, pitch2, half2); };
+        // tiles th3, th3+2, ... of this wave, in passes of exactly NPT tiles (compile-time: no branch
+        // between MFMAs); counts that occur: 2 (z crop), 4, 5 = 3 + 2
+        auto run3 = [&](auto npt_c, int tb) {
+            constexpr int NPT = decltype(npt_c)::value;
+            int base[NPT];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int op = 16 * (tb + 2 * i) + px;
                 const int y = op >> w3_log2, x = op - (y << w3_log2);
-                v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
-                map3[(4 * ot + q) * npix3 + (y + lr_first) * pitch3 + ((x & 1) ? half3 + 1 + (x >> 1) : (x >> 1))] = v;
+                base[i] = 2 * y * pitch2 + x;
+            }
+            f4 acc[NPT][1];
+            const f4 bv = ld4(b3 + 16 * ot3 + 4 * q);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) acc[i][0] = bv;
+            vtc::mma_pass<1, NPT, NCH3, NCH3>(in3, base, w3a, 0, off3, acc);
+            if (16 * ot3 + 4 * q < 24) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const int op = 16 * (tb + 2 * i) + px;
+                    const int y = op >> w3_log2, x = op - (y << w3_log2);
+                    f4 v = acc[i][0];
+                    v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
+                    map3[(4 * ot3 + q) * npix3 + (y + lr_first) * pitch3 + ((x & 1) ? half3 + 1 + (x >> 1) : (x >> 1))] = v;
+                }
             }
         };
-        // the first computed layer-3 row (local lr_first) reads layer-2 local rows 2*lr_first ..
-        conv_s2_mfma<3, 2, 4>(map2 + 2 * lr_first * pitch2, npix2, pitch2, half2, w3_log2, ntiles, w3img, b3, wave, lane,
-                              store3);
+        int left = (ntiles - th3 + 1) >> 1, tb = th3;
+        while (left >= 4) { run3(std::integral_constant<int, 4>{}, tb); tb += 8; left -= 4; }
+        if (left == 3) run3(std::integral_constant<int, 3>{}, tb);
+        else if (left == 2) run3(std::integral_constant<int, 2>{}, tb);
+        else if (left == 1) run3(std::integral_constant<int, 1>{}, tb);
     }
     __syncthreads();
     // ---- layer 4 (24 -> 48) + pos-embed -> token rows -------------------------------------------
-    {
+    if (!(skip & 8)) {
         const int w4_log2 = ilog2(S4);
-        const int ntiles = (R4 * S4 + 15) >> 4;
-        const int npx = R4 * S4;
-        auto store4 = [&](int t, int ot, f4 v) {
-            const int op = 16 * t + px;
-            if (op < npx) {
-                const int tk = y4_0 * S4 + op;                 // token index inside this crop
+        const int npx = R4 * S4;                            // 16 or 32 output pixels (checked on the host)
+        const int ntiles = (npx + 15) >> 4;
+        auto off4 = [&](int c) { return s2_chunk_off<6>(c, q, npix3, pitch3, half3); };
+        f4 acc[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ot = 0; ot < 3; ++ot) acc[i][ot] = splat4(0.f);
+        auto run4 = [&](auto npt_c, auto n_c) {
+            constexpr int NPT = decltype(npt_c)::value, N = decltype(n_c)::value;
+            int base[NPT];
+            f4 a4[NPT][3];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int op = 16 * i + px;
+                const int y = op >> w4_log2, x = op - (y << w4_log2);
+                base[i] = 2 * y * pitch3 + x;
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot) a4[i][ot] = splat4(0.f);
+            }
+            vtc::mma_pass<3, NPT, 4, N>(map3, base, w4a, c4_0, off4, a4);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot) acc[i][ot] = a4[i][ot];
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        if (ntiles == 2) { if (c4_n == 4) run4(I2{}, I4{}); else run4(I2{}, I3{}); }
+        else             { if (c4_n == 4) run4(I1{}, I4{}); else run4(I1{}, I3{}); }
+        // partial sums -> [wave][tile < ntiles][ot][lane] in map2's space (dead since layer 3's
+        // barrier; 4 * ntiles * 3 KiB <= 3 * npix2 * 16 B for every supported band, host-checked)
+        f4* part = map2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (i < ntiles)
+#pragma unroll
+                for (int ot = 0; ot < 3; ++ot) part[((wave * ntiles + i) * 3 + ot) * 64 + lane] = acc[i][ot];
+        __syncthreads();
+        // six (tile, ot) results; wave w finalises items w and w + 4, summing the four k-quarters in order
+        for (int item = wave; item < 2 * 3; item += 4) {
+            const int i = item / 3, ot = item - 3 * i;
+            const int op = 16 * i + px;
+            if (i < ntiles && op < npx) {
+                f4 v = ld4(b4 + 16 * ot + 4 * q);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v = v + part[((w * ntiles + i) * 3 + ot) * 64 + lane];
+                const int tk = y4_0 * S4 + op;              // token index inside this crop
                 const f4 pe = ld4(pos + (size_t)tk * 48 + 16 * ot + 4 * q);
                 st4(tokens + ((size_t)b * L + tok_off + tk) * 48 + 16 * ot + 4 * q, v + pe);
             }
-        };
-        conv_s2_mfma<6, 3, 1>(map3, npix3, pitch3, half3, w4_log2, ntiles, w4img, b4, wave, lane, store4);
+        }
     }
 }
 

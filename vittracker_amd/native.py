@@ -125,8 +125,11 @@ class Graph:
         _check(lib().vt_graph_launch(self._h, _stream(stream)), "vt_graph_launch")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().vt_graph_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vt_graph_destroy(self._h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
             self._h = None
 
 
@@ -146,11 +149,15 @@ class Model:
         self.max_batch = max_batch
 
     def close(self):
-        if getattr(self, "_h", None):
-            lib().vt_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.vt_destroy(self._h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        self.close()
 
     def load_state_dict(self, sd: dict):
         """sd: name -> numpy array / torch tensor, reference ckpt['net'] layout (strict=False)."""
