@@ -122,6 +122,15 @@ int vt_query(const vt_model* m, int32_t* len_z, int32_t* len_x, int32_t* feat_sz
  * asymmetric B and checks the operand / result lane maps the kernels rely on. 0 = as assumed. */
 int vt_selftest_mfma(void* stream);
 
+/* Development probe (synchronises; not part of the hot path): sustained shader clock in MHz
+ * under a dense f32-MFMA loop with `waves_per_simd` waves on every SIMD, the cycles one SIMD
+ * spends per v_mfma_f32_16x16x4_f32, and the wall time of the probe launch.  Used by bench.py to
+ * state the clock the roofline fraction was measured at. */
+int vt_probe_clock(int32_t iters, int32_t waves_per_simd, double* mhz, double* cycles_per_mfma, double* wall_us);
+/* Development aid: with VT_DBG_STAMPS=1 in the environment at vt_create the transformer-block kernel
+ * records s_memtime at its phase boundaries; this copies them out ([B][5][64] uint64, synchronises). */
+int vt_debug_stamps(vt_model* m, int32_t B, unsigned long long* host_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the transformer-block kernel from in-kernel s_memtime stamps
+(VT_DBG_STAMPS=1): average shader cycles per phase, per wave index."""
+import os
+import sys
+os.environ["VT_DBG_STAMPS"] = "1"
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from vittracker_amd import native, synth
+
+geom = sys.argv[1] if len(sys.argv) > 1 else "G128"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+tz, tx = {"G128": (64, 128), "G256": (128, 256)}[geom]
+m = native.Model(tz, tx, max_batch=B)
+m.load_state_dict(synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2))
+z, x = synth.synth_inputs(1, B, tz, tx)
+tok = m.stem(torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda())
+for _ in range(3):
+    m.blocks(tok)
+torch.cuda.synchronize()
+buf = np.zeros((B, 5, 64), dtype=np.uint64)
+native._check(native.lib().vt_debug_stamps(m._h, B, buf.ctypes.data), "stamps")
+if geom == "G128":   # WLDS variant: a barrier splits the MLP
+    names = sum([[f"b{k} (load)ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} ln2+fc1+gelu01",
+                   f"b{k} barrier3", f"b{k} fc2+gelu2", f"b{k} barrier4"] for k in range(3)], []) + ["tail"]
+else:
+    names = sum([[f"b{k} (load)ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} mlp"] for k in range(3)], []) + ["tail"]
+nw = 5 if geom == "G128" else 4
+st = buf[:, :nw, :len(names) + 1].astype(np.int64)
+d = np.diff(st, axis=2)
+print(f"{geom} B={B}: mean shader cycles per phase, by wave index (total per wave in last row)")
+print("phase".ljust(16) + "".join(f"wave{w:>2d}".rjust(10) for w in range(nw)))
+for k, n in enumerate(names[:d.shape[2]]):
+    print(n.ljust(20) + "".join(f"{d[:, w, k].mean():10.0f}" for w in range(nw)))
+tot = (st[:, :, d.shape[2]] - st[:, :, 0])
+print("total".ljust(16) + "".join(f"{tot[:, w].mean():10.0f}" for w in range(nw)))

@@ -69,6 +69,7 @@ struct vt_model {
     DevBuf tokens, feat;
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
+    unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
 };
 
 struct vt_graph {
@@ -244,11 +245,11 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     return VT_OK;
 }
 
-template <int NT, int NW, int TPW>
+template <int NT, int NW, int TPW, bool WLDS>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
-    const size_t lds = (size_t)2 * NT * vtb::NC * 64 * sizeof(f4);
-    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
-                       resid, m->len_z, m->cfg.depth, nblocks);
+    const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4);
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+                       resid, m->len_z, m->cfg.depth, nblocks, env_int("VT_DBG_SKIP_TILE", -1), m->dbg_stamps);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -256,8 +257,8 @@ int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int n
 int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid) {
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     switch (m->L / 16) {
-        case 5: return launch_blocks<5, 5, 1>(m, st, tokens, B, nblocks, feat, resid);
-        case 20: return launch_blocks<20, 4, 5>(m, st, tokens, B, nblocks, feat, resid);
+        case 5: return launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid);
+        case 20: return launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid);
         default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
     }
 }
@@ -302,6 +303,31 @@ __global__ void mfma_selftest_kernel(const float* A, const float* Bm, float* D) 
     for (int r = 0; r < 4; ++r) D[(4 * q + r) * 16 + rc] = acc[r];
 }
 
+// Clock / MFMA-rate probe: every wave runs `iters` rounds of 8 independent v_mfma_f32_16x16x4_f32
+// and stamps the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime).
+__global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ src, int iters,
+                                                    unsigned long long* __restrict__ stamps, float* __restrict__ sink) {
+    f4 acc[8];
+    const float a0 = src[threadIdx.x], b0 = src[256 + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = splat4(0.001f * j);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[j], 0, 0, 0);
+    }
+    f4 sum = splat4(0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum = sum + acc[j];
+    sink[(size_t)blockIdx.x * 256 + threadIdx.x] = sum.x + sum.y + sum.z + sum.w;   // data dependence on every MFMA
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t k = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+        stamps[k] = t1 - t0;
+        stamps[k + 1] = r1 - r0;
+    }
+}
+
 }  // namespace
 
 // =========================================================================================== ABI
@@ -344,13 +370,21 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->pred, B * 4);
     A(m->hann, B * 4);
     A(m->conf, B);
+    if (!rc && env_int("VT_DBG_STAMPS", 0)) {
+        if (hipMalloc(reinterpret_cast<void**>(&m->dbg_stamps), B * 5 * 64 * sizeof(unsigned long long)) != hipSuccess)
+            rc = fail(VT_ERR_HIP, "hipMalloc(stamps) failed");
+    }
     if (!rc) rc = upload(m->window, hann2d(m->F));
     if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
     if (!rc) {
         // > 64 KiB of dynamic LDS needs an explicit opt-in
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 5, 1, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -373,6 +407,7 @@ void vt_destroy(vt_model* m) {
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    if (m->dbg_stamps) (void)hipFree(m->dbg_stamps);
     delete m;
 }
 
@@ -546,6 +581,56 @@ void vt_graph_destroy(vt_graph* g) {
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
+}
+
+int vt_debug_stamps(vt_model* m, int32_t B, unsigned long long* host_out) {
+    // Development aid: copies the block kernel's phase stamps ([B][5 waves][32]) of the last launch.
+    if (!m || !m->dbg_stamps || !host_out) return fail(VT_ERR_STATE, "stamps are off (set VT_DBG_STAMPS=1 before vt_create)");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, m->dbg_stamps, (size_t)B * 5 * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return VT_OK;
+}
+
+int vt_probe_clock(int32_t iters, int32_t waves_per_simd, double* mhz, double* cycles_per_mfma, double* wall_us) {
+    // Development probe (not on the hot path; synchronises): sustained shader clock under a dense
+    // f32-MFMA loop and the cycles one SIMD spends per v_mfma_f32_16x16x4_f32.
+    if (iters < 1 || waves_per_simd < 1 || waves_per_simd > 4) return fail(VT_ERR_ARG, "bad probe arguments");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, 0));
+    const int nwg = prop.multiProcessorCount * waves_per_simd;
+    float *src = nullptr, *sink = nullptr;
+    unsigned long long* st = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&src), 512 * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), (size_t)nwg * 256 * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&st), (size_t)nwg * 8 * sizeof(unsigned long long)));
+    std::vector<float> h(512);
+    for (int i = 0; i < 512; ++i) h[i] = 0.25f + 0.001f * (float)((i * 37) % 101);
+    HIP_TRY(hipMemcpy(src, h.data(), 512 * sizeof(float), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(probe_kernel, dim3(nwg), dim3(256), 0, nullptr, src, iters, st, sink);   // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(probe_kernel, dim3(nwg), dim3(256), 0, nullptr, src, iters, st, sink);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> hs((size_t)nwg * 8);
+    HIP_TRY(hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> f, c;
+    for (size_t k = 0; k < hs.size(); k += 2) {
+        f.push_back((double)hs[k] / (double)hs[k + 1] * 100.0);
+        c.push_back((double)hs[k] / ((double)iters * 8.0) / waves_per_simd);
+    }
+    std::sort(f.begin(), f.end());
+    std::sort(c.begin(), c.end());
+    if (mhz) *mhz = f[f.size() / 2];
+    if (cycles_per_mfma) *cycles_per_mfma = c[c.size() / 2];
+    if (wall_us) *wall_us = ms * 1e3;
+    (void)hipFree(src); (void)hipFree(sink); (void)hipFree(st);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return VT_OK;
 }
 
 int vt_selftest_mfma(void* stream) {

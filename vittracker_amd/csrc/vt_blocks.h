@@ -49,6 +49,28 @@ __device__ __forceinline__ f4 wimg(const float* __restrict__ base, int tile, int
     return ld4(base + (size_t)tile * 256 + lane * 4);
 }
 
+// Burst-load N weight operand images (tile indices first + j * stride) and pin the burst where it
+// is written, so it is in flight while the code that follows (LayerNorm, the previous GEMM's MFMAs)
+// executes instead of stalling the GEMM that consumes it.
+template <int N>
+__device__ __forceinline__ void wburst(f4 (&a)[N], const float* __restrict__ base, int first, int stride, int lane) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) a[j] = wimg(base, first + j * stride, lane);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Tell the scheduler to issue `n` rounds of {1 MFMA, `valu` VALU/transcendental ops}: a wave can
+// issue ~6 independent vector ops in the 32-cycle shadow of each v_mfma_f32_16x16x4_f32, which is
+// how GELU of one hidden group hides behind the MFMAs of the next.
+template <int N, int VALU_PER_MFMA>
+__device__ __forceinline__ void interleave_mfma_valu() {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);
+    }
+}
+
 // LayerNorm of one token held as NC operand-image chunks; g/b point at gamma/beta (C floats).
 __device__ __forceinline__ void layer_norm_img(const f4 (&x)[NC], f4 (&h)[NC], const float* __restrict__ g,
                                                const float* __restrict__ b, int q) {
@@ -70,18 +92,57 @@ __device__ __forceinline__ void layer_norm_img(const f4 (&x)[NC], f4 (&h)[NC], c
     }
 }
 
+// Weight staging through LDS (WLDS).  Every wave of a workgroup needs every weight tile of a GEMM.
+// Fetched per wave from L2 that is NW x 110 KB per block and workgroup -- with 256 workgroups reading
+// the same lines at the same time the L2 channels, not the MFMA pipe, set the pace (measured: 48
+// MFMAs took ~3000 cycles instead of 1536).  With WLDS each 1 KiB operand image is copied ONCE per
+// workgroup by LDS-DMA (global_load_lds_dwordx4: lane-linear, exactly the image layout) into one of
+// two staging buffers, one GEMM ahead of its use, and the A operands are ds_read_b128 from there:
+//     buffer A: qkv (27 tiles) -> fc1 (36) -> next block's qkv ...
+//     buffer B: proj (9 tiles) -> fc2 (36) -> next block's proj ...
+// A buffer is refilled only after the barrier that ends its last reader; __syncthreads() waits
+// for the DMA (vmcnt) before it releases the readers.
+constexpr int WBUF_TILES = NH * NC;   // 36: fc1 / fc2
+
+__device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ src, int ntiles, int w, int nw, int lane) {
+    for (int t = w; t < ntiles; t += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)t * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + t * 64), 16, 0, 0);
+}
+
+// One GEMM stage: NCHUNK k-chunks, N independent accumulator chains.  `opa(c, a)` fills the N
+// per-chain operands of chunk c, `opb(c)` returns the operand all chains share.  The operands of
+// chunk c+1 are requested BEFORE the MFMAs of chunk c are issued (explicit double buffer): left to
+// itself the scheduler puts each ds_read / global_load right in front of its first use and the wave
+// pays the full read latency once per chunk (measured: ~47 instead of 32 cycles per MFMA).
+template <int NCHUNK, int N, bool SHARED_IS_B, typename OpA, typename OpS>
+__device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
+    f4 a[2][N];
+    opa(0, a[0]);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        if (c + 1 < NCHUNK) opa(c + 1, a[(c + 1) & 1]);
+        if constexpr (SHARED_IS_B) mfma4_shared_b(a[c & 1], ops(c), acc);
+        else mfma4_shared_a(ops(c), a[c & 1], acc);
+    }
+}
+
 // NT = token tiles per frame (L / 16), NW = waves per workgroup, TPW = tiles per wave.
-template <int NT, int NW, int TPW>
+template <int NT, int NW, int TPW, bool WLDS>
 __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
                                                          float* __restrict__ resid,          // (B, L, C) or null
-                                                         int len_z, int depth_total, int nblocks) {
+                                                         int len_z, int depth_total, int nblocks,
+                                                         int dbg_skip_tile,                  // timing experiments only (-1)
+                                                         unsigned long long* __restrict__ stamps) {   // diagnostic, null in production
     static_assert(NW * TPW >= NT, "tiles must be covered");
     constexpr int L = NT * 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]
     f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
+    f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
+    f4* Wb = Wa + WBUF_TILES * 64;                         // WLDS: [36][64] staging buffer B
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -89,38 +150,58 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
     const int tok = lane & 15, q = lane >> 4;
     const float scale = 0.14433756729740643f;  // 48^-0.5  (head_dim ** -0.5, attn.py:15)
 
+    // diagnostic phase stamps: shader-clock reads by lane 0 of every wave, [b][w][64]
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (stamps != nullptr) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (lane == 0) stamps[((size_t)b * NW + w) * 64 + nstamp] = t;
+            ++nstamp;
+        }
+    };
+    stamp();
+    if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
+
     f4 x[TPW][NC];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int T = w + NW * i;
-        if (T < NT) {
+        if (T < NT && T != dbg_skip_tile) {
             const float* src = tokens + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
 #pragma unroll
             for (int c = 0; c < NC; ++c) x[i][c] = ld4(src + 16 * c);
         }
     }
+    if constexpr (WLDS) __syncthreads();
 
     for (int blk = 0; blk < nblocks; ++blk) {
         const float* __restrict__ P = params + (size_t)blk * BLOCK_STRIDE;
+        // weight operand image `t` of each GEMM: from the staging buffers (WLDS) or straight from L2
+        auto w_qkv = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_WQKV, t, lane); };
+        auto w_proj = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_WPROJ, t, lane); };
+        auto w_fc1 = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_W1, t, lane); };
+        auto w_fc2 = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_W2, t, lane); };
+        if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
+
         f4 qr[TPW][NC];
         // ---- LN1 + QKV; publish K / V^T images ------------------------------------------------
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT) {
+            if (T < NT && T != dbg_skip_tile) {
                 f4 h[NC];
                 layer_norm_img(x[i], h, P + O_LN1G, P + O_LN1B, q);
                 {   // q and k: 6 independent chains, rows = features, cols = tokens (B = h shared)
                     f4 acc[2 * NC];
 #pragma unroll
                     for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(P + O_BQKV + 16 * ot + 4 * q);
+                    gemm_stage<NC, 2 * NC, true>(
+                        [&](int c, f4 (&a)[2 * NC]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        f4 a[2 * NC];
-#pragma unroll
-                        for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = wimg(P + O_WQKV, ot * NC + c, lane);
-                        mfma4_shared_b(a, h[c], acc);
-                    }
+                            for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = w_qkv(ot * NC + c);
+                        },
+                        [&](int c) { return h[c]; }, acc);
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) {
                         qr[i][ot] = acc[ot];
@@ -131,19 +212,21 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                     f4 acc[NC];
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
+                    gemm_stage<NC, NC, false>(
+                        [&](int c, f4 (&bw)[NC]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        f4 bw[NC];
-#pragma unroll
-                        for (int ot = 0; ot < NC; ++ot) bw[ot] = wimg(P + O_WQKV, (2 * NC + ot) * NC + c, lane);
-                        mfma4_shared_a(h[c], bw, acc);
-                    }
+                            for (int ot = 0; ot < NC; ++ot) bw[ot] = w_qkv((2 * NC + ot) * NC + c);
+                        },
+                        [&](int c) { return h[c]; }, acc);
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
                 }
             }
         }
-        __syncthreads();
+        stamp();            // QKV done
+        __syncthreads();    // K/V published; proj weights landed; buffer A free
+        stamp();
+        if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
         // output, proj and MLP never reach the head (vit_dist.py:126 keeps the search rows only),
         // so those tiles stop after publishing K / V -- unless the caller asked for the residual.
@@ -152,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT && !(last_skip_z && 16 * T < len_z)) {
+            if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                 f4 s[NT];
                 float m = -3.0e38f;
                 constexpr int JG = 5;                    // key tiles per group = independent chains
@@ -162,13 +245,12 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                     f4 acc[JG];
 #pragma unroll
                     for (int j = 0; j < JG; ++j) acc[j] = splat4(0.f);
+                    gemm_stage<NC, JG, true>(
+                        [&](int c, f4 (&a)[JG]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        f4 a[JG];
-#pragma unroll
-                        for (int j = 0; j < JG; ++j) a[j] = Kimg[((j0 + j) * NC + c) * 64 + lane];
-                        mfma4_shared_b(a, qr[i][c], acc);
-                    }
+                            for (int j = 0; j < JG; ++j) a[j] = Kimg[((j0 + j) * NC + c) * 64 + lane];
+                        },
+                        [&](int c) { return qr[i][c]; }, acc);
 #pragma unroll
                     for (int j = 0; j < JG; ++j) {
                         acc[j] = acc[j] * splat4(scale);     // (q @ k^T) * scale, attn.py:40
@@ -190,65 +272,144 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                 f4 o[NC];
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
+                gemm_stage<NT, NC, true>(                // O^T = V^T P^T: 3 feature-tile chains share B = P_J
+                    [&](int J, f4 (&a)[NC]) {
 #pragma unroll
-                for (int J = 0; J < NT; ++J) {           // O^T = V^T P^T: 3 feature-tile chains share B = P_J
-                    f4 a[NC];
-#pragma unroll
-                    for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J) * 64 + lane];
-                    mfma4_shared_b(a, s[J], o);
-                }
+                        for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J) * 64 + lane];
+                    },
+                    [&](int J) { return s[J]; }, o);
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_BPROJ + 16 * ot + 4 * q);
+                gemm_stage<NC, NC, true>(
+                    [&](int c, f4 (&a)[NC]) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    f4 a[NC];
-#pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(P + O_WPROJ, ot * NC + c, lane);
-                    mfma4_shared_b(a, o[c], x[i]);
-                }
+                        for (int ot = 0; ot < NC; ++ot) a[ot] = w_proj(ot * NC + c);
+                    },
+                    [&](int c) { return o[c]; }, x[i]);
             }
         }
-        __syncthreads();   // every wave is done reading K/V before the next block overwrites them
+        stamp();            // attention + proj done
+        __syncthreads();    // K/V and buffer B free; fc1 weights landed
+        stamp();
+        if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
         // ---- LN2 + MLP (residual add) ---------------------------------------------------------
+        // fc1 -> GELU -> fc2 in three groups of HG = 4 hidden tiles, software-pipelined so GELU (VALU)
+        // of one group issues in the shadow of the next group's MFMAs:
+        //   fc1(g0) | fc1(g1) || GELU(g0) | fc1(g2) || GELU(g1) | fc2(k in g0) || GELU(g2) | fc2(g1) | fc2(g2)
+        constexpr int HG = 4;
+        static_assert(NH / HG == 3, "pipeline written for 12 hidden tiles");
+        constexpr int NHID = WLDS ? TPW : 1;       // without the mid-MLP barrier each tile finishes before the next starts
+        f4 hid[NHID][NH];
+        f4 acc2[NHID][HG];
+        auto fc1 = [&](const f4 (&h)[NC], int g, f4 (&acc)[HG]) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int T = w + NW * i;
-            if (T < NT && !(last_skip_z && 16 * T < len_z)) {
-                f4 h[NC];
-                layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
-                f4 hid[NH];
-                constexpr int HG = 6;                    // hidden tiles per group = independent chains
+            for (int j = 0; j < HG; ++j) acc[j] = ld4(P + O_B1 + 16 * (HG * g + j) + 4 * q);
+            gemm_stage<NC, HG, true>(
+                [&](int c, f4 (&a)[HG]) {
 #pragma unroll
-                for (int g = 0; g < NH; g += HG) {
-                    f4 acc[HG];
+                    for (int j = 0; j < HG; ++j) a[j] = w_fc1((HG * g + j) * NC + c);
+                },
+                [&](int c) { return h[c]; }, acc);
+        };
+        auto gelu_group = [&](const f4 (&acc)[HG], f4 (&hd)[NH], int g) {
 #pragma unroll
-                    for (int j = 0; j < HG; ++j) acc[j] = ld4(P + O_B1 + 16 * (g + j) + 4 * q);
+            for (int j = 0; j < HG; ++j)
+                hd[HG * g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
+        };
+        auto fc2 = [&](const f4 (&hd)[NH], int g, f4 (&xo)[NC]) {
+            gemm_stage<HG, NC, true>(
+                [&](int cc, f4 (&a)[NC]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        f4 a[HG];
+                    for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + HG * g + cc);
+                },
+                [&](int cc) { return hd[HG * g + cc]; }, xo);
+        };
+        auto mlp_first = [&](int i, int hi) {          // LN2, fc1 (all groups), GELU of groups 0 and 1
+            f4 h[NC];
+            layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
 #pragma unroll
-                        for (int j = 0; j < HG; ++j) a[j] = wimg(P + O_W1, (g + j) * NC + c, lane);
-                        mfma4_shared_b(a, h[c], acc);
+            for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
+            f4 acc0[HG], acc1[HG];
+            fc1(h, 0, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            fc1(h, 1, acc1);
+            gelu_group(acc0, hid[hi], 0);
+            interleave_mfma_valu<12 * HG, 5>();
+            __builtin_amdgcn_sched_barrier(0);
+            fc1(h, 2, acc2[hi]);
+            gelu_group(acc1, hid[hi], 1);
+            interleave_mfma_valu<12 * HG, 5>();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mlp_second = [&](int i, int hi) {         // fc2 (+ GELU of group 2 behind its first third)
+            fc2(hid[hi], 0, x[i]);
+            gelu_group(acc2[hi], hid[hi], 2);
+            interleave_mfma_valu<12 * HG, 5>();
+            __builtin_amdgcn_sched_barrier(0);
+            fc2(hid[hi], 1, x[i]);
+            fc2(hid[hi], 2, x[i]);
+        };
+        if constexpr (WLDS) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int T = w + NW * i;
+                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first(i, i);
+            }
+            stamp();            // fc1 done
+            __syncthreads();    // fc2 weights landed; buffer A free
+            if (blk + 1 < nblocks) stage_tiles(Wa, P + BLOCK_STRIDE + O_WQKV, 9 * NC, w, NW, lane);   // next block's qkv
+            stamp();
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int T = w + NW * i;
+                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second(i, i);
+            }
+        } else {
+            // many tiles per wave (G256): plain per-tile MLP in two groups of 6 hidden tiles -- the
+            // pipelined form above costs registers this variant does not have
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int T = w + NW * i;
+                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+                    f4 h[NC];
+                    layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
+                    f4 hd[NH];
+                    constexpr int G6 = 6;
+#pragma unroll
+                    for (int g = 0; g < NH; g += G6) {
+                        f4 acc[G6];
+#pragma unroll
+                        for (int j = 0; j < G6; ++j) acc[j] = ld4(P + O_B1 + 16 * (g + j) + 4 * q);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            f4 a[G6];
+#pragma unroll
+                            for (int j = 0; j < G6; ++j) a[j] = w_fc1((g + j) * NC + c);
+                            mfma4_shared_b(a, h[c], acc);
+                        }
+#pragma unroll
+                        for (int j = 0; j < G6; ++j)
+                            hd[g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
                     }
 #pragma unroll
-                    for (int j = 0; j < HG; ++j)
-                        hid[g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
-                }
+                    for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
+                    for (int c = 0; c < NH; ++c) {
+                        f4 a[NC];
 #pragma unroll
-                for (int c = 0; c < NH; ++c) {
-                    f4 a[NC];
-#pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(P + O_W2, ot * NH + c, lane);
-                    mfma4_shared_b(a, hid[c], x[i]);
+                        for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + c);
+                        mfma4_shared_b(a, hd[c], x[i]);
+                    }
                 }
             }
         }
+        stamp();            // MLP done
+        if constexpr (WLDS) __syncthreads();   // buffer B free; next qkv weights landed
     }
 
+    stamp();
     // ---- epilogue: optional residual dump; final LayerNorm on the search tokens ----------------
     const float* __restrict__ PF = params + (size_t)depth_total * BLOCK_STRIDE;   // norm.weight, norm.bias
     const int Lx = L - len_z;

@@ -60,42 +60,65 @@ struct Geo {
 };
 
 // One 3x3 stride-1 conv + bias + ReLU between two LDS maps on MFMA (core: vt_conv.h).
+// Work split over the 4 waves: a 2-output-tile layer (conv1) gives each wave ONE output tile and
+// half of the pixel tiles, so the waves stream different weights; 1-output-tile layers split the
+// pixel tiles four ways.  Weights move in passes of <= 9 chunks, double-buffered: prefetch() issues
+// pass 0 (callable a whole layer early -- weights do not depend on activations) and run() requests
+// pass p+1 before the MFMAs of pass p.
 template <int CIN, int COUT, int F>
-__device__ __forceinline__ void conv3x3_relu_mfma(const f4* in_map, f4* out_map, const float* __restrict__ wimg,
-                                                  const float* __restrict__ bias, int wave, int lane) {
+struct HeadConv {
     using G = Geo<F>;
-    constexpr int NQ = CIN / 4, NCH = nchunks(CIN), NOT = ntiles(COUT), NPT = G::NPT;
-    constexpr int MAXC = NOT == 1 ? (NCH <= 9 ? NCH : 9) : 7;       // <= 56-72 VGPRs of weights per pass
-    const int q = lane >> 4;
-    int base[NPT];
+    static constexpr int NQ = CIN / 4, NCH = nchunks(CIN), NOT = ntiles(COUT);
+    static constexpr bool SPLIT_OT = NOT == 2;
+    static constexpr int NPT = SPLIT_OT ? G::NT / 2 : G::NT / 4;
+    static constexpr int TSTEP = SPLIT_OT ? 2 : 4;
+    static constexpr int MAXC = NCH < 9 ? NCH : 9;
+    static constexpr int NPASS = (NCH + MAXC - 1) / MAXC;
+    static_assert(NOT <= 2, "layers here have at most 2 output tiles");
+    f4 a[2][MAXC][1];
+
+    __device__ __forceinline__ const float* wbase(const float* __restrict__ wimg, int wave) const {
+        return wimg + (SPLIT_OT ? (size_t)(wave & 1) * NCH * 256 : 0);
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ wimg, int wave, int lane) {
+        vtc::load_weights<1, MAXC, NCH>(wbase(wimg, wave), 0, MAXC, lane, a[0]);
+    }
+    __device__ __forceinline__ void run(const f4* in_map, f4* out_map, const float* __restrict__ wimg,
+                                        const float* __restrict__ bias, int wave, int lane) {
+        const int q = lane >> 4;
+        const int ot = SPLIT_OT ? (wave & 1) : 0, tfirst = SPLIT_OT ? (wave >> 1) : wave;
+        int base[NPT];
 #pragma unroll
-    for (int i = 0; i < NPT; ++i) base[i] = G::tap00(wave + 4 * i, lane);
-    f4 acc[NPT][NOT];
-#pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
+        for (int i = 0; i < NPT; ++i) base[i] = G::tap00(tfirst + TSTEP * i, lane);
+        f4 acc[NPT][1];
         const f4 bv = ld4(bias + 16 * ot + 4 * q);
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) acc[i][ot] = bv;
-    }
-    auto off = [&](int c) {
-        int tap, icq;
-        vtc::decode_quad<NQ>(4 * c + q, tap, icq);
-        const int dy = tap / 3, dx = tap - 3 * dy;
-        return icq * G::NPIX + dy * G::P + dx;
-    };
-    vtc::conv_all_chunks<NOT, NPT, MAXC, NCH>(in_map, base, wimg, lane, off, acc);
+        for (int i = 0; i < NPT; ++i) acc[i][0] = bv;
+        auto off = [&](int c) {
+            int tap, icq;
+            vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            return icq * G::NPIX + dy * G::P + dx;
+        };
+        const float* __restrict__ wb = wbase(wimg, wave);
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot) {
+        for (int p = 0; p < NPASS; ++p) {
+            constexpr int LASTN = NCH - (NPASS - 1) * MAXC;
+            if (p + 1 < NPASS)
+                vtc::load_weights<1, MAXC, NCH>(wb, (p + 1) * MAXC, p + 2 < NPASS ? MAXC : LASTN, lane, a[(p + 1) & 1]);
+            if (p + 1 < NPASS) vtc::mma_pass<1, NPT, MAXC, MAXC>(in_map, base, a[p & 1], p * MAXC, off, acc);
+            else vtc::mma_pass<1, NPT, MAXC, LASTN>(in_map, base, a[p & 1], p * MAXC, off, acc);
+        }
         if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
-                f4 v = acc[i][ot];
+                f4 v = acc[i][0];
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 out_map[(4 * ot + q) * G::NPIX + base[i] + G::P + 1] = v;
             }
         }
     }
-}
+};
 
 // grid (B, 3): tower 0 = ctr, 1 = offset, 2 = size.   feat: (B, F*F, 48) normalised search tokens.
 template <int F>
@@ -113,6 +136,11 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
 
+    HeadConv<C, W1, F> c1;
+    HeadConv<W1, 16, F> c2;
+    HeadConv<16, 8, F> c3;
+    HeadConv<8, 4, F> c4;
+    c1.prefetch(tw + O_W1, wave, lane);        // first weight burst flies during the map set-up
     if (!(skip & 1))
         for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += 256) in_map[i] = splat4(0.f);
     __syncthreads();
@@ -124,13 +152,16 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
             ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
     }
     __syncthreads();
-    if (!(skip & 4)) conv3x3_relu_mfma<C, W1, F>(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
+    c2.prefetch(tw + O_W2, wave, lane);        // each layer's first burst is requested a layer early
+    if (!(skip & 4)) c1.run(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
+    c3.prefetch(tw + O_W3, wave, lane);
     __syncthreads();
-    if (!(skip & 8)) conv3x3_relu_mfma<W1, 16, F>(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
+    if (!(skip & 8)) c2.run(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
+    c4.prefetch(tw + O_W4, wave, lane);
     __syncthreads();
-    if (!(skip & 16)) conv3x3_relu_mfma<16, 8, F>(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
+    if (!(skip & 16)) c3.run(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
     __syncthreads();
-    if (!(skip & 16)) conv3x3_relu_mfma<8, 4, F>(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
+    if (!(skip & 16)) c4.run(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
     __syncthreads();
     // 1x1 conv + activation (head.py:187,194,200-201)
     for (int pix = threadIdx.x; pix < F * F; pix += 256) {

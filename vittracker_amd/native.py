@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvittrack_hip.so")
 SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
-    "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma",
+    "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps",
 ]
 
 
@@ -70,6 +70,8 @@ def lib():
     L.vt_graph_destroy.restype = None
     L.vt_query.argtypes = [vp] + [C.POINTER(i32)] * 4
     L.vt_selftest_mfma.argtypes = [vp]
+    L.vt_probe_clock.argtypes = [i32, i32] + [C.POINTER(C.c_double)] * 3
+    L.vt_debug_stamps.argtypes = [vp, i32, vp]
     _lib = L
     return L
 
@@ -94,6 +96,13 @@ def _stream(stream):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return C.c_void_p(s.cuda_stream)
+
+
+def probe_clock(iters=20000, waves_per_simd=1):
+    """(shader MHz under dense f32 MFMA, SIMD cycles per MFMA, wall us) -- development probe."""
+    v = [C.c_double() for _ in range(3)]
+    _check(lib().vt_probe_clock(iters, waves_per_simd, *[C.byref(x) for x in v]), "vt_probe_clock")
+    return tuple(x.value for x in v)
 
 
 def selftest_mfma():
