@@ -96,6 +96,18 @@ class Runner:
         return {"stem": t_stem, "blocks": t_blocks, "head": t_head}
 
 
+def pmc_traffic(geom, B):
+    """HBM bytes per launch of the block kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, in bytes,
+    measured at this geometry and batch).  None when no matching measurement is committed."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = t.get(f"{geom}_B{B}", {}).get("vtb::blocks_kernel")
+        return None if e is None else int(e["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(budget_s=20.0):
     """Reference-equivalent CPU path: the torch restatement of the module graph (oracle/), timed
     like tracking/profile_model_cpu.py:36-49 (bs=1 loop) and at bs=256, bounded to ~budget_s."""
@@ -211,7 +223,14 @@ def main():
             ach = flop / (st["blocks"] * 1e-6) / 1e12
             line["roofline"] = {"kernel": "vtb::blocks_kernel", "bound": "mfma", "achieved": round(ach, 2),
                                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-                                "traffic": None, "flop_per_launch": flop, "avg_launch_us": round(st["blocks"], 2)}
+                                "traffic": pmc_traffic(a.geom, B), "flop_per_launch": flop,
+                                "avg_launch_us": round(st["blocks"], 2)}
+            try:   # the clock the fraction was measured at (dense f32-MFMA probe, 1 wave / SIMD)
+                mhz, cpm, _ = r.native.probe_clock(20000, 1)
+                line["roofline"]["probe_clock_mhz"] = round(mhz)
+                line["roofline"]["probe_cycles_per_mfma"] = round(cpm, 2)
+            except Exception:  # noqa: BLE001
+                pass
             line["stages_us"] = {k: round(v, 2) for k, v in st.items()}
             line["stages_frac_fp32_peak"] = {k: round(2 * macs[k] * B / (st[k] * 1e-6) / 1e12 / PEAK_FP32_TFLOPS, 4) for k in st}
             if a.geom == "G128" and world == 1:
