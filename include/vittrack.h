@@ -109,6 +109,23 @@ int vt_head(vt_model* m, const float* feat_dev, int32_t B, void* stream, const v
 int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, const float* offset_dev,
                 int32_t B, void* stream, float* bbox_dev, float* max_score_dev);
 
+/* --- the steps either side of the network in track(), on the device ---- */
+/* sample_target(image, state, factor, output_sz) + Preprocessor.process
+ * (lib/train/data/processing_utils.py:12-79; lib/test/tracker/data_utils.py:11-17) for B sequences:
+ * frames_dev (B,H,W,3) uint8, states_dev (B,4) double [x,y,w,h] -> crops_dev (B,3,T,T) fp32
+ * normalised with mean3/std3 (host, 3 floats each) and resize_factor_dev (B) double = T / crop_sz.
+ * Crop geometry in double with Python's round-half-even; resize = OpenCV INTER_LINEAR uint8
+ * fixed-point scheme. */
+int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const double* states_dev, double factor,
+            int32_t out_size, const float* mean3, const float* std3, int32_t B, void* stream, float* crops_dev,
+            double* resize_factor_dev);
+/* The tail of Vit_dist.track (lib/test/tracker/vit_dist.py:107-111,150-156; clip_box,
+ * lib/utils/box_ops.py:97-106): scale the windowed box back to image pixels, map it to the frame,
+ * clip with `margin`, and overwrite states_dev (B,4) double in place.  No host sync: a sequence can
+ * run as back-to-back graph replays with its state on the device. */
+int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resize_factor_dev, int32_t search_size,
+                    int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev);
+
 /* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,
                      const vt_outputs* out, vt_graph** g);

@@ -1,0 +1,103 @@
+"""GPU: the rows either side of the network: device crop / resize / normalise,
+device state update, and the lock-step batched tracker -- each against the host statement of the same
+reference code (vittracker_amd/host_ops.py, the tracker plugin)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _nat(geom=(128, 256), B=8):
+    from vittracker_amd import native, synth
+    m = native.Model(geom[0], geom[1], max_batch=B)
+    m.load_state_dict(synth.synth_state_dict(0, len_z=(geom[0] // 16) ** 2, len_x=(geom[1] // 16) ** 2))
+    return m
+
+
+def _host_crop(frame, box, factor, T):
+    """sample_target + Preprocessor.process, float32 like the reference (data_utils.py:13-14)."""
+    from vittracker_amd.host_ops import sample_target
+    crop, rf, _ = sample_target(frame, list(box), factor, output_sz=T)
+    mean = np.array(MEAN, np.float32).reshape(3, 1, 1)
+    std = np.array(STD, np.float32).reshape(3, 1, 1)
+    t = crop.astype(np.float32).transpose(2, 0, 1)
+    # torch on a GPU computes `img / 255.0` as img * float32(1/255) (division by a CPU scalar)
+    return ((t * (np.float32(1.0) / np.float32(255.0))) - mean) / std, rf
+
+
+@pytest.mark.parametrize("T,factor", [(256, 4.0), (128, 2.0), (64, 2.0)])
+def test_device_crop_equals_host_crop(T, factor):
+    """Boxes inside, across every border, tiny, huge, fractional (round-half-even cases included)."""
+    import torch
+    rs = np.random.RandomState(0)
+    H, W = 120, 160
+    boxes = [[40, 30, 20, 24], [-5, -8, 30, 30], [130, 90, 40, 36], [0, 0, 8, 8], [60.5, 41.5, 11, 7],
+             [150, 110, 30, 30], [10.25, 77.75, 5.5, 3.25], [70, 50, 90, 80]]
+    B = len(boxes)
+    frames = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    m = _nat(B=B)
+    crops, rf = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), factor, T, MEAN, STD)
+    crops, rf = crops.cpu().numpy(), rf.cpu().numpy()
+    for b in range(B):
+        want, want_rf = _host_crop(frames[b], boxes[b], factor, T)
+        assert rf[b] == want_rf
+        np.testing.assert_array_equal(crops[b], want, err_msg=f"box {boxes[b]}")
+
+
+def test_device_state_update_equals_host_tail():
+    import torch
+    from vittracker_amd.host_ops import clip_box
+    from oracle import vt_oracle_np as onp
+    rs = np.random.RandomState(1)
+    B, H, W, S = 64, 480, 640, 256
+    states = np.concatenate([rs.uniform(-20, 600, (B, 2)), rs.uniform(5, 200, (B, 2))], 1)
+    hann = rs.uniform(0, 1, (B, 4)).astype(np.float32)
+    rf = S / np.ceil(np.sqrt(states[:, 2] * states[:, 3]) * 4.0)
+    m = _nat(B=B)
+    st = torch.from_numpy(states.copy()).cuda()
+    m.update_state(torch.from_numpy(hann).cuda(), torch.from_numpy(rf).cuda(), st, S, H, W, margin=10)
+    got = st.cpu().numpy()
+    for b in range(B):
+        pred = (torch.from_numpy(hann[b]).view(1, 4).mean(dim=0) * S / float(rf[b])).tolist()   # tracker :107-109
+        want = clip_box(onp.map_box_back(list(states[b]), pred, float(rf[b]), S), H, W, margin=10)
+        np.testing.assert_allclose(got[b], want, rtol=1e-6, atol=1e-6)
+
+
+def test_batched_tracker_equals_independent_plugin_trackers():
+    """B sequences in lock-step with device-resident state == B separate Vit_dist plugin objects."""
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.parameter import vit_dist as P
+    from vittracker_amd.tracker.vit_dist import get_tracker_class
+    os.environ["VITTRACK_PRJ_DIR"] = REPO
+    p = P.parameters("vit_48_h32_noKD")
+    p.allow_synthetic_weights = True
+    p.debug = 0
+    B, n, H, W = 4, 5, 200, 260
+    rs = np.random.RandomState(3)
+    vids = rs.randint(0, 256, (n, B, H, W, 3)).astype(np.uint8)
+    boxes0 = [[60 + 10 * b, 50 + 5 * b, 40, 30 + 2 * b] for b in range(B)]
+    bt = BatchedVitTracker(p, B)
+    bt.initialize(vids[0], boxes0)
+    singles = []
+    for b in range(B):
+        t = get_tracker_class()(p, "synthetic")
+        t.initialize(vids[0, b], {"init_bbox": list(map(float, boxes0[b]))})
+        singles.append(t)
+    for f in range(1, n):
+        out = bt.track(vids[f])
+        for b in range(B):
+            o = singles[b].track(vids[f, b])
+            np.testing.assert_allclose(out["target_bbox"][b].numpy(), o["target_bbox"], rtol=1e-6, atol=1e-5)
+            assert abs(float(out["confidence"][b]) - o["confidence"]) < 1e-6
+    # no-sync mode: same final state after replaying the sequence without reading back per frame
+    bt2 = BatchedVitTracker(p, B)
+    bt2.initialize(vids[0], boxes0)
+    for f in range(1, n):
+        last = bt2.track(vids[f], sync=False)
+    np.testing.assert_array_equal(last["target_bbox"].cpu().numpy(), out["target_bbox"].numpy())

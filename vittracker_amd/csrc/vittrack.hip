@@ -18,6 +18,7 @@
 #include "vt_blocks.h"
 #include "vt_head.h"
 #include "vt_stem.h"
+#include "vt_track.h"
 
 namespace {
 
@@ -550,6 +551,29 @@ int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, cons
     if (!m || !score_dev || !size_dev || !offset_dev || !bbox_dev || B < 1) return fail(VT_ERR_ARG, "bad argument");
     return run_decode(m, static_cast<hipStream_t>(stream), score_dev, size_dev, offset_dev, nullptr, B, bbox_dev, nullptr,
                       max_score_dev);
+}
+
+int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const double* states_dev, double factor,
+            int32_t out_size, const float* mean3, const float* std3, int32_t B, void* stream, float* crops_dev,
+            double* resize_factor_dev) {
+    if (!m || !frames_dev || !states_dev || !crops_dev || !resize_factor_dev || !mean3 || !std3)
+        return fail(VT_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || out_size < 1 || !(factor > 0.0)) return fail(VT_ERR_ARG, "bad crop arguments");
+    dim3 grid((out_size * out_size + 255) / 256, B);
+    hipLaunchKernelGGL(vtt::crop_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), frames_dev, H, W,
+                       states_dev, factor, out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], crops_dev,
+                       resize_factor_dev);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resize_factor_dev, int32_t search_size,
+                    int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev) {
+    if (!m || !hann_boxes_dev || !resize_factor_dev || !states_dev || B < 1) return fail(VT_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(vtt::update_state_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       hann_boxes_dev, resize_factor_dev, search_size, H, W, margin, B, states_dev);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
 }
 
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, const vt_outputs* out,

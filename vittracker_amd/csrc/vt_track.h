@@ -1,0 +1,114 @@
+// vt_track.h -- the steps either side of the network in Vit_dist.track(), on the device.
+//
+// crop_kernel replaces, per sequence, sample_target (lib/train/data/processing_utils.py:12-79:
+// square crop of side ceil(sqrt(w*h)*factor) around the previous box, zero padding, cv.resize to
+// T x T) followed by Preprocessor.process (lib/test/tracker/data_utils.py:11-17: /255, -mean, /std,
+// HWC -> NCHW).  update_state_kernel replaces the tail of track() (lib/test/tracker/vit_dist.py:
+// 107-111,150-156 and clip_box, lib/utils/box_ops.py:97-106).
+//
+// Numerics follow the reference's host code: box / crop geometry in double (Python floats),
+// round-half-even for the crop origin (Python round()), OpenCV's INTER_LINEAR uint8 path in 11-bit
+// fixed point (weights = round(w * 2048), horizontal pass in int, vertical pass
+// (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2), float32 normalisation in the reference's
+// operation order (as torch executes it on a GPU).  Integer stages are bit-exact against the host port in vittracker_amd/host_ops.py
+// (which is itself unpinned against cv2: SURVEY.md 8(f) rank 1).
+#pragma once
+#include "vt_common.h"
+
+namespace vtt {
+
+struct CropGeom {     // per sequence, written by crop_kernel's first lane for update_state_kernel
+    double resize_factor;   // T / crop_sz
+};
+
+// Source index and 11-bit weights of output coordinate d (OpenCV resize, linear, pixel centres).
+__device__ __forceinline__ void lin_coeff(int d, int src, double scale, int& s0, int& s1, int& a0, int& a1) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src - 1) { s = src - 1; f = 0.f; }
+    a1 = (int)rintf(f * 2048.f);
+    a0 = (int)rintf((1.f - f) * 2048.f);
+    s0 = s;
+    s1 = s + 1 < src ? s + 1 : src - 1;
+}
+
+// grid (ceil(T*T/256), B); frames (B,H,W,3) uint8; states (B,4) double [x,y,w,h]; out (B,3,T,T) float.
+__global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restrict__ frames, int H, int W,
+                                                   const double* __restrict__ states, double factor, int T,
+                                                   float m0, float m1, float m2, float s0, float s1, float s2,
+                                                   float* __restrict__ out, double* __restrict__ resize_factor) {
+    const int b = blockIdx.y;
+    const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
+    int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
+    if (crop_sz < 1) crop_sz = 1;                 // the reference raises 'Too small bounding box.' here
+    const int x1 = (int)rint(bx + 0.5 * bw - crop_sz * 0.5);     // Python round(): half to even
+    const int y1 = (int)rint(by + 0.5 * bh - crop_sz * 0.5);
+    const int x2 = x1 + crop_sz, y2 = y1 + crop_sz;
+    // valid source range of the padded crop (the reference's pad formula keeps max(x2 - W + 1, 0)
+    // columns on the right, i.e. drops the last image column when the crop reaches the border)
+    const int vx0 = x1 < 0 ? 0 : x1, vx1 = x2 - (x2 - W + 1 > 0 ? x2 - W + 1 : 0);
+    const int vy0 = y1 < 0 ? 0 : y1, vy1 = y2 - (y2 - H + 1 > 0 ? y2 - H + 1 : 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) resize_factor[b] = (double)T / (double)crop_sz;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * T) return;
+    const int oy = idx / T, ox = idx - oy * T;
+    const double scale = (double)crop_sz / (double)T;
+    int sx0, sx1, ax0, ax1, sy0, sy1, by0, by1;
+    lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0, ax1);
+    lin_coeff(oy, crop_sz, scale, sy0, sy1, by0, by1);
+    const unsigned char* fr = frames + (size_t)b * H * W * 3;
+    auto px = [&](int cy, int cx, int c) -> int {      // pixel (cy, cx) of the zero-padded crop
+        const int yy = y1 + cy, xx = x1 + cx;
+        return (yy >= vy0 && yy < vy1 && xx >= vx0 && xx < vx1) ? (int)fr[((size_t)yy * W + xx) * 3 + c] : 0;
+    };
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int r0 = px(sy0, sx0, c) * ax0 + px(sy0, sx1, c) * ax1;
+        const int r1 = px(sy1, sx0, c) * ax0 + px(sy1, sx1, c) * ax1;
+        int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        // torch's CUDA `tensor / 255.0` multiplies by the float reciprocal (div_true with a CPU scalar);
+        // Preprocessor.process runs on the GPU, so that is the reference arithmetic
+        // Three separately rounded ops, as three torch kernels: the empty asm keeps hipcc from
+        // contracting the multiply and the subtraction into one fma (the _rn intrinsics do not).
+        float scaled = (float)v * (1.0f / 255.0f);
+        asm volatile("" : "+v"(scaled));
+        float centred = scaled - mean[c];
+        asm volatile("" : "+v"(centred));
+        out[(((size_t)b * 3 + c) * T + oy) * T + ox] = centred / stdv[c];
+    }
+}
+
+// One thread per sequence.  hann_boxes (B,4) float [cx,cy,w,h] in [0,1]; states (B,4) double in/out.
+__global__ void update_state_kernel(const float* __restrict__ hann_boxes, const double* __restrict__ resize_factor,
+                                    int search_size, int H, int W, int margin, int B, double* __restrict__ states) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double rf = resize_factor[b];
+    // (pred_boxes.mean(0) * search_size / resize_factor).tolist(): float32 arithmetic, then Python floats
+    double p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = (double)((hann_boxes[4 * b + k] * (float)search_size) / (float)rf);
+    // map_box_back (lib/test/tracker/vit_dist.py:150-156)
+    const double sx = states[4 * b + 0], sy = states[4 * b + 1], sw = states[4 * b + 2], sh = states[4 * b + 3];
+    const double cx_prev = sx + 0.5 * sw, cy_prev = sy + 0.5 * sh;
+    const double half_side = 0.5 * search_size / rf;
+    const double cx_real = p[0] + (cx_prev - half_side), cy_real = p[1] + (cy_prev - half_side);
+    double bx1 = cx_real - 0.5 * p[2], by1 = cy_real - 0.5 * p[3];
+    const double w = p[2], h = p[3];
+    // clip_box(box, H, W, margin) (lib/utils/box_ops.py:97-106)
+    double bx2 = bx1 + w, by2 = by1 + h;
+    bx1 = fmin(fmax(0.0, bx1), (double)(W - margin));
+    bx2 = fmin(fmax((double)margin, bx2), (double)W);
+    by1 = fmin(fmax(0.0, by1), (double)(H - margin));
+    by2 = fmin(fmax((double)margin, by2), (double)H);
+    states[4 * b + 0] = bx1;
+    states[4 * b + 1] = by1;
+    states[4 * b + 2] = fmax((double)margin, bx2 - bx1);
+    states[4 * b + 3] = fmax((double)margin, by2 - by1);
+}
+
+}  // namespace vtt

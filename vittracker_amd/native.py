@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvittrack_hip.so")
 SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
-    "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps",
+    "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
 ]
 
 
@@ -72,6 +72,8 @@ def lib():
     L.vt_selftest_mfma.argtypes = [vp]
     L.vt_probe_clock.argtypes = [i32, i32] + [C.POINTER(C.c_double)] * 3
     L.vt_debug_stamps.argtypes = [vp, i32, vp]
+    L.vt_crop.argtypes = [vp, vp, i32, i32, vp, C.c_double, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp]
+    L.vt_update_state.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     _lib = L
     return L
 
@@ -229,6 +231,33 @@ class Model:
         st = out.struct()
         _check(lib().vt_head(self._h, _ptr(feat), B, _stream(stream), C.byref(st)), "vt_head")
         return out
+
+    # ---- pre / post steps of track() on the device
+    def crop(self, frames, states, factor, out_size, mean, std, out=None, resize_factor=None, stream=None):
+        """frames (B,H,W,3) uint8 cuda, states (B,4) float64 cuda -> (crops (B,3,T,T) fp32, resize_factor (B) fp64)."""
+        import torch
+        if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+                and frames.shape[3] == 3):
+            raise VtError("frames must be a contiguous (B,H,W,3) uint8 tensor on the GPU")
+        if not (states.is_cuda and states.dtype == torch.float64 and states.is_contiguous()):
+            raise VtError("states must be a contiguous (B,4) float64 tensor on the GPU")
+        B, H, W, _ = frames.shape
+        if out is None:
+            out = torch.empty(B, 3, out_size, out_size, device=frames.device)
+        if resize_factor is None:
+            resize_factor = torch.empty(B, dtype=torch.float64, device=frames.device)
+        m3 = (C.c_float * 3)(*[float(v) for v in mean])
+        s3 = (C.c_float * 3)(*[float(v) for v in std])
+        _check(lib().vt_crop(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor),
+                             out_size, m3, s3, B, _stream(stream), _ptr(out), C.c_void_p(resize_factor.data_ptr())),
+               "vt_crop")
+        return out, resize_factor
+
+    def update_state(self, hann_boxes, resize_factor, states, search_size, H, W, margin=10, stream=None):
+        B = states.shape[0]
+        _check(lib().vt_update_state(self._h, _ptr(hann_boxes), C.c_void_p(resize_factor.data_ptr()), search_size, H, W,
+                                     margin, B, _stream(stream), C.c_void_p(states.data_ptr())), "vt_update_state")
+        return states
 
     def cal_bbox(self, score, size, offset, stream=None):
         import torch
