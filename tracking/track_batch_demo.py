@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""End-to-end lock-step tracking of B synthetic sequences (frames uploaded from the host every step):
+the real-pipeline number next to bench.py's device-step number.
+
+    python tracking/track_batch_demo.py --batch 256 --frames 50 --size 480 640
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="vit_48_h32_noKD")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
+    a = ap.parse_args()
+    import torch
+    os.environ.setdefault("VITTRACK_PRJ_DIR", ROOT)
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.parameter import vit_dist as P
+    p = P.parameters(a.config)
+    p.allow_synthetic_weights = True
+    H, W = a.size
+    rs = np.random.RandomState(0)
+    B = a.batch
+    frames = rs.randint(0, 256, (2, B, H, W, 3)).astype(np.uint8)      # two alternating frame sets
+    boxes = np.stack([rs.uniform(50, W - 150, B), rs.uniform(50, H - 150, B), rs.uniform(30, 90, B), rs.uniform(30, 90, B)], 1)
+    bt = BatchedVitTracker(p, B)
+    bt.initialize(frames[0], boxes)
+    for f in range(3):
+        bt.track(frames[f & 1], sync=False)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for f in range(a.frames):
+        out = bt.track(frames[f & 1], sync=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"{B} sequences x {a.frames} frames of {H}x{W}: {B * a.frames / dt:.0f} frames/s end to end "
+          f"(host frames -> H2D -> crop -> graph -> state update), {dt / a.frames * 1e3:.2f} ms per step; "
+          f"H2D {B * H * W * 3 / 1e6:.0f} MB per step")
+    dev = torch.from_numpy(frames).cuda()
+    t0 = time.time()
+    for f in range(a.frames):
+        out = bt.track(dev[f & 1], sync=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"frames already on the device: {B * a.frames / dt:.0f} frames/s, {dt / a.frames * 1e3:.3f} ms per step")
+    print("last boxes[0]:", out["target_bbox"][0].tolist())
+
+
+if __name__ == "__main__":
+    main()
