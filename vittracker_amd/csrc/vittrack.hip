@@ -70,7 +70,13 @@ struct vt_model {
     DevBuf tokens, feat;
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
+    hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra capture streams for graph chains
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
+    // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
+    int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
+    int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
+    int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
 };
 
 struct vt_graph {
@@ -221,9 +227,12 @@ StemPlan stem_plan_default(int T) {
     }
 }
 
-int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens) {
+int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0) {
+    // f0: first frame of this slice in the model workspace (z, x, tokens already point at the slice)
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
-    const StemPlan px = stem_plan(Tx), pz = stem_plan(Tz);
+    float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
+    float* const act_z = m->act_z.p + f0 * (size_t)(Tz / 4) * (Tz / 4) * 12;
+    const StemPlan px{m->plan_r2[0], m->plan_r4[0]}, pz{m->plan_r2[1], m->plan_r4[1]};
     for (const auto& pr : {std::make_pair(Tx, px), std::make_pair(Tz, pz)}) {
         const int T = pr.first, r2 = pr.second.r2, r4 = pr.second.r4;
         const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
@@ -232,16 +241,16 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
             3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64)
             return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
     }
-    vts::CropA ax{x, m->act_x.p, Tx, px.r2, (Tx / 4) / px.r2}, az{z, m->act_z.p, Tz, pz.r2, (Tz / 4) / pz.r2};
+    vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
     const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
     hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
-                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, env_int("VT_SKIP_STEM_A", 0));
+                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
     HIP_TRY(hipGetLastError());
-    vts::CropB bx{m->act_x.p, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
-    vts::CropB bz{m->act_z.p, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
+    vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
+    vts::CropB bz{act_z, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
     const size_t lds_b = std::max(vts::stem_b_lds_bytes(Tx / 4, px.r4), vts::stem_b_lds_bytes(Tz / 4, pz.r4));
     hipLaunchKernelGGL(vts::stem_b_kernel, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
-                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, env_int("VT_SKIP_STEM_B", 0));
+                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, m->skip_stem_b);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -250,7 +259,7 @@ template <int NT, int NW, int TPW, bool WLDS>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
     const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4);
     hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
-                       resid, m->len_z, m->cfg.depth, nblocks, env_int("VT_DBG_SKIP_TILE", -1), m->dbg_stamps);
+                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -258,7 +267,9 @@ int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int n
 int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid) {
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     switch (m->L / 16) {
-        case 5: return launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid);
+        case 5:
+            return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid)
+                                  : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid);
         case 20: return launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid);
         default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
     }
@@ -271,19 +282,21 @@ int run_decode(vt_model* m, hipStream_t st, const float* score, const float* siz
     return VT_OK;
 }
 
-int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o) {
-    float* score = (o && o->score_map) ? o->score_map : m->score.p;
-    float* size = (o && o->size_map) ? o->size_map : m->size.p;
-    float* offset = (o && o->offset_map) ? o->offset_map : m->offset.p;
-    float* pred = (o && o->pred_boxes) ? o->pred_boxes : m->pred.p;
-    float* hann = (o && o->hann_boxes) ? o->hann_boxes : m->hann.p;
-    float* conf = (o && o->conf) ? o->conf : m->conf.p;
+int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o, size_t f0 = 0) {
+    // outputs of the slice starting at frame f0 (feat already points at the slice)
+    const size_t n = (size_t)m->len_x;
+    float* score = ((o && o->score_map) ? o->score_map : m->score.p) + f0 * n;
+    float* size = ((o && o->size_map) ? o->size_map : m->size.p) + f0 * 2 * n;
+    float* offset = ((o && o->offset_map) ? o->offset_map : m->offset.p) + f0 * 2 * n;
+    float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
+    float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
+    float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
     if (m->F == 8) {
         hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
-                           feat, m->head.p, score, size, offset, env_int("VT_SKIP_HEAD", 0));
+                           feat, m->head.p, score, size, offset, m->skip_head);
     } else if (m->F == 16) {
         hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::Geo<16>::LDS_BYTES,
-                           st, feat, m->head.p, score, size, offset, env_int("VT_SKIP_HEAD", 0));
+                           st, feat, m->head.p, score, size, offset, m->skip_head);
     } else {
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
     }
@@ -371,6 +384,16 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->pred, B * 4);
     A(m->hann, B * 4);
     A(m->conf, B);
+    m->skip_stem_a = env_int("VT_SKIP_STEM_A", 0);
+    m->skip_stem_b = env_int("VT_SKIP_STEM_B", 0);
+    m->skip_head = env_int("VT_SKIP_HEAD", 0);
+    m->dbg_skip_tile = env_int("VT_DBG_SKIP_TILE", -1);
+    m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
+    m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
+    {
+        const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
+        m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
+    }
     if (!rc && env_int("VT_DBG_STAMPS", 0)) {
         if (hipMalloc(reinterpret_cast<void**>(&m->dbg_stamps), B * 5 * 64 * sizeof(unsigned long long)) != hipSuccess)
             rc = fail(VT_ERR_HIP, "hipMalloc(stamps) failed");
@@ -378,6 +401,11 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     if (!rc) rc = upload(m->window, hann2d(m->F));
     if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
         rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
+    for (int i = 0; i < 3 && !rc; ++i)
+        if (hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->join_ev[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail(VT_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+    if (!rc && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) rc = fail(VT_ERR_HIP, "hipEventCreate failed");
     if (!rc) {
         // > 64 KiB of dynamic LDS needs an explicit opt-in
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5, false>),
@@ -408,6 +436,11 @@ void vt_destroy(vt_model* m) {
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+    for (int i = 0; i < 3; ++i) {
+        if (m->side_stream[i]) (void)hipStreamDestroy(m->side_stream[i]);
+        if (m->join_ev[i]) (void)hipEventDestroy(m->join_ev[i]);
+    }
+    if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
     if (m->dbg_stamps) (void)hipFree(m->dbg_stamps);
     delete m;
 }
@@ -576,15 +609,47 @@ int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resi
     return VT_OK;
 }
 
+// One slice [f0, f0 + nb) of a batch through the whole step, on stream st.
+static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0, int nb, hipStream_t st,
+                         const vt_outputs* out) {
+    const size_t Tz = m->cfg.template_size, Tx = m->cfg.search_size;
+    float* tok = m->tokens.p + f0 * m->L * 48;
+    float* feat = m->feat.p + f0 * m->len_x * 48;
+    int rc;
+    if ((rc = run_stem(m, z + f0 * 3 * Tz * Tz, x + f0 * 3 * Tx * Tx, nb, st, tok, f0))) return rc;
+    if ((rc = run_blocks(m, tok, nb, -1, st, feat, nullptr))) return rc;
+    return run_head(m, feat, nb, st, out, f0);
+}
+
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, const vt_outputs* out,
                      vt_graph** g) {
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!g) return fail(VT_ERR_ARG, "null graph out");
+    // The batch is captured as NCH independent chains over frame slices (fork / join with events):
+    // the five kernels of one slice then overlap the kernels of the others instead of running
+    // strictly one after another with a fixed start-up cost and a tail each.
+    int nch = m->graph_chains;   // measured: 2 chains cost +12 % at G128/B=256, -3 % at G256; default 1
+    nch = std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
-    rc = vt_forward(m, z_dev, x_dev, B, m->cap_stream, out);
+    rc = VT_OK;
+    if (nch == 1) {
+        rc = vt_forward(m, z_dev, x_dev, B, m->cap_stream, out);
+    } else {
+        if (hipEventRecord(m->fork_ev, m->cap_stream) != hipSuccess) rc = fail(VT_ERR_HIP, "hipEventRecord(fork)");
+        for (int c = 1; c < nch && !rc; ++c)
+            if (hipStreamWaitEvent(m->side_stream[c - 1], m->fork_ev, 0) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamWaitEvent(fork)");
+        for (int c = 0; c < nch && !rc; ++c) {
+            const size_t f0 = (size_t)B * c / nch, f1 = (size_t)B * (c + 1) / nch;
+            rc = forward_slice(m, z_dev, x_dev, f0, (int)(f1 - f0), c == 0 ? m->cap_stream : m->side_stream[c - 1], out);
+        }
+        for (int c = 1; c < nch; ++c) {   // always join, even after an error, so the capture can end
+            (void)hipEventRecord(m->join_ev[c - 1], m->side_stream[c - 1]);
+            (void)hipStreamWaitEvent(m->cap_stream, m->join_ev[c - 1], 0);
+        }
+    }
     e = hipStreamEndCapture(m->cap_stream, &vg->graph);
     if (rc) { if (vg->graph) (void)hipGraphDestroy(vg->graph); delete vg; return rc; }
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }

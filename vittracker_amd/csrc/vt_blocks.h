@@ -115,26 +115,42 @@ __device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ s
 // chunk c+1 are requested BEFORE the MFMAs of chunk c are issued (explicit double buffer): left to
 // itself the scheduler puts each ds_read / global_load right in front of its first use and the wave
 // pays the full read latency once per chunk (measured: ~47 instead of 32 cycles per MFMA).
-template <int NCHUNK, int N, bool SHARED_IS_B, typename OpA, typename OpS>
+template <int NCHUNK, int N, bool SHARED_IS_B, bool PRELOAD_ALL = true, typename OpA, typename OpS>
 __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
-    f4 a[2][N];
-    opa(0, a[0]);
+    if constexpr (PRELOAD_ALL && NCHUNK * N <= 24) {
+        // small stage: request every operand first and pin the requests ahead of the MFMAs -- one
+        // read round trip per stage instead of one per chunk
+        f4 a[NCHUNK][N];
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        if (c + 1 < NCHUNK) opa(c + 1, a[(c + 1) & 1]);
-        if constexpr (SHARED_IS_B) mfma4_shared_b(a[c & 1], ops(c), acc);
-        else mfma4_shared_a(ops(c), a[c & 1], acc);
+        for (int c = 0; c < NCHUNK; ++c) opa(c, a[c]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            if constexpr (SHARED_IS_B) mfma4_shared_b(a[c], ops(c), acc);
+            else mfma4_shared_a(ops(c), a[c], acc);
+        }
+    } else {
+        f4 a[2][N];
+        opa(0, a[0]);
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            if (c + 1 < NCHUNK) opa(c + 1, a[(c + 1) & 1]);
+            if constexpr (SHARED_IS_B) mfma4_shared_b(a[c & 1], ops(c), acc);
+            else mfma4_shared_a(ops(c), a[c & 1], acc);
+        }
     }
 }
 
 // NT = token tiles per frame (L / 16), NW = waves per workgroup, TPW = tiles per wave.
+// (min waves per SIMD: the lean 5-wave variant is capped at 168 VGPRs so two or three workgroups share a CU)
 template <int NT, int NW, int TPW, bool WLDS>
-__global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
+__global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
                                                          float* __restrict__ resid,          // (B, L, C) or null
                                                          int len_z, int depth_total, int nblocks,
-                                                         int dbg_skip_tile,                  // timing experiments only (-1)
+                                                         int dbg_skip_tile,                  // timing experiments only (-1);
+                                                                                             // bits 8.. = ablation flags
                                                          unsigned long long* __restrict__ stamps) {   // diagnostic, null in production
     static_assert(NW * TPW >= NT, "tiles must be covered");
     constexpr int L = NT * 16;
@@ -149,6 +165,9 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = lane & 15, q = lane >> 4;
     const float scale = 0.14433756729740643f;  // 48^-0.5  (head_dim ** -0.5, attn.py:15)
+    // timing ablations (wrong results by design): 1 = GELU -> identity, 2 = exp -> identity, 4 = no MFMA in the MLP
+    const int ablate = dbg_skip_tile >= 256 ? (dbg_skip_tile >> 8) : 0;
+    if (dbg_skip_tile >= 256) dbg_skip_tile = (dbg_skip_tile & 255) == 255 ? -1 : (dbg_skip_tile & 255);
 
     // diagnostic phase stamps: shader-clock reads by lane 0 of every wave, [b][w][64]
     int nstamp = 0;
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                     f4 acc[2 * NC];
 #pragma unroll
                     for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(P + O_BQKV + 16 * ot + 4 * q);
-                    gemm_stage<NC, 2 * NC, true>(
+                    gemm_stage<NC, 2 * NC, true, WLDS>(
                         [&](int c, f4 (&a)[2 * NC]) {
 #pragma unroll
                             for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = w_qkv(ot * NC + c);
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                     f4 acc[NC];
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
-                    gemm_stage<NC, NC, false>(
+                    gemm_stage<NC, NC, false, WLDS>(
                         [&](int c, f4 (&bw)[NC]) {
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) bw[ot] = w_qkv((2 * NC + ot) * NC + c);
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                     f4 acc[JG];
 #pragma unroll
                     for (int j = 0; j < JG; ++j) acc[j] = splat4(0.f);
-                    gemm_stage<NC, JG, true>(
+                    gemm_stage<NC, JG, true, WLDS>(
                         [&](int c, f4 (&a)[JG]) {
 #pragma unroll
                             for (int j = 0; j < JG; ++j) a[j] = Kimg[((j0 + j) * NC + c) * 64 + lane];
@@ -263,8 +282,11 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
 #pragma unroll
                 for (int J = 0; J < NT; ++J) {
                     f4 e;
-                    e.x = __expf(s[J].x - m); e.y = __expf(s[J].y - m);
-                    e.z = __expf(s[J].z - m); e.w = __expf(s[J].w - m);
+                    if (ablate & 2) e = s[J] - splat4(m);
+                    else {
+                        e.x = __expf(s[J].x - m); e.y = __expf(s[J].y - m);
+                        e.z = __expf(s[J].z - m); e.w = __expf(s[J].w - m);
+                    }
                     s[J] = e;
                     den += hsum4(e);
                 }
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                 f4 o[NC];
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
-                gemm_stage<NT, NC, true>(                // O^T = V^T P^T: 3 feature-tile chains share B = P_J
+                gemm_stage<NT, NC, true, WLDS>(                // O^T = V^T P^T: 3 feature-tile chains share B = P_J
                     [&](int J, f4 (&a)[NC]) {
 #pragma unroll
                         for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J) * 64 + lane];
@@ -282,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
                 for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_BPROJ + 16 * ot + 4 * q);
-                gemm_stage<NC, NC, true>(
+                gemm_stage<NC, NC, true, WLDS>(
                     [&](int c, f4 (&a)[NC]) {
 #pragma unroll
                         for (int ot = 0; ot < NC; ++ot) a[ot] = w_proj(ot * NC + c);
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
         auto fc1 = [&](const f4 (&h)[NC], int g, f4 (&acc)[HG]) {
 #pragma unroll
             for (int j = 0; j < HG; ++j) acc[j] = ld4(P + O_B1 + 16 * (HG * g + j) + 4 * q);
-            gemm_stage<NC, HG, true>(
+            gemm_stage<NC, HG, true, WLDS>(
                 [&](int c, f4 (&a)[HG]) {
 #pragma unroll
                     for (int j = 0; j < HG; ++j) a[j] = w_fc1((HG * g + j) * NC + c);
@@ -316,10 +338,10 @@ __global__ __launch_bounds__(NW * 64) void blocks_kernel(const float* __restrict
         auto gelu_group = [&](const f4 (&acc)[HG], f4 (&hd)[NH], int g) {
 #pragma unroll
             for (int j = 0; j < HG; ++j)
-                hd[HG * g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
+                hd[HG * g + j] = (ablate & 1) ? acc[j] : f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
         };
         auto fc2 = [&](const f4 (&hd)[NH], int g, f4 (&xo)[NC]) {
-            gemm_stage<HG, NC, true>(
+            gemm_stage<HG, NC, true, WLDS>(
                 [&](int cc, f4 (&a)[NC]) {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + HG * g + cc);
