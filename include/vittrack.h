@@ -145,7 +145,7 @@ int vt_selftest_mfma(void* stream);
  * state the clock the roofline fraction was measured at. */
 int vt_probe_clock(int32_t iters, int32_t waves_per_simd, double* mhz, double* cycles_per_mfma, double* wall_us);
 /* Development aid: with VT_DBG_STAMPS=1 in the environment at vt_create the transformer-block kernel
- * records s_memtime at its phase boundaries; this copies them out ([B][5][64] uint64, synchronises). */
+ * records s_memtime at its phase boundaries; this copies them out ([B][8][64] uint64, wave-major, synchronises). */
 int vt_debug_stamps(vt_model* m, int32_t B, unsigned long long* host_out);
 
 #ifdef __cplusplus

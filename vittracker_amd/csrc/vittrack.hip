@@ -75,6 +75,7 @@ struct vt_model {
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
     int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
+    int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
     int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
 };
@@ -255,10 +256,12 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     return VT_OK;
 }
 
-template <int NT, int NW, int TPW, bool WLDS>
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
-    const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4);
-    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+    const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
+                       (size_t)vtb::small_floats(m->cfg.depth) * sizeof(float) +
+                       (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 16 : 0);
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
                        resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps);
     HIP_TRY(hipGetLastError());
     return VT_OK;
@@ -268,9 +271,12 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     switch (m->L / 16) {
         case 5:
+            if (m->blocks_bal) return launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid);
             return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid)
                                   : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid);
-        case 20: return launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid);
+        case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
+            return m->blocks_bal ? launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid)
+                                 : launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid);
         default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
     }
 }
@@ -315,6 +321,10 @@ __global__ void mfma_selftest_kernel(const float* A, const float* Bm, float* D) 
     }
     f4 acc = mfma4(a, b, splat4(0.f));
     for (int r = 0; r < 4; ++r) D[(4 * q + r) * 16 + rc] = acc[r];
+    // permlane-swap reductions over the 4 lanes sharing (lane & 15): sum must be 15 (rc + 1), max 8 (rc + 1)
+    const float v = (float)((1 << q) * (rc + 1));
+    D[256 + lane] = quad_sum(v);
+    D[320 + lane] = quad_max(v);
 }
 
 // Clock / MFMA-rate probe: every wave runs `iters` rounds of 8 independent v_mfma_f32_16x16x4_f32
@@ -390,12 +400,13 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->dbg_skip_tile = env_int("VT_DBG_SKIP_TILE", -1);
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
+    m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
     }
     if (!rc && env_int("VT_DBG_STAMPS", 0)) {
-        if (hipMalloc(reinterpret_cast<void**>(&m->dbg_stamps), B * 5 * 64 * sizeof(unsigned long long)) != hipSuccess)
+        if (hipMalloc(reinterpret_cast<void**>(&m->dbg_stamps), B * 8 * 64 * sizeof(unsigned long long)) != hipSuccess)
             rc = fail(VT_ERR_HIP, "hipMalloc(stamps) failed");
     }
     if (!rc) rc = upload(m->window, hann2d(m->F));
@@ -676,7 +687,7 @@ int vt_debug_stamps(vt_model* m, int32_t B, unsigned long long* host_out) {
     // Development aid: copies the block kernel's phase stamps ([B][5 waves][32]) of the last launch.
     if (!m || !m->dbg_stamps || !host_out) return fail(VT_ERR_STATE, "stamps are off (set VT_DBG_STAMPS=1 before vt_create)");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host_out, m->dbg_stamps, (size_t)B * 5 * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host_out, m->dbg_stamps, (size_t)B * 8 * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VT_OK;
 }
 
@@ -724,7 +735,7 @@ int vt_probe_clock(int32_t iters, int32_t waves_per_simd, double* mhz, double* c
 
 int vt_selftest_mfma(void* stream) {
     // exact small integers; B is asymmetric so a transposed read or write cannot pass
-    std::vector<float> A(256), Bm(256), D(256, -1.f), ref(256, 0.f);
+    std::vector<float> A(256), Bm(256), D(384, -1.f), ref(256, 0.f);
     for (int i = 0; i < 16; ++i)
         for (int k = 0; k < 16; ++k) {
             A[i * 16 + k] = (float)((i * 3 + k * 5) % 7 - 3);
@@ -736,18 +747,20 @@ int vt_selftest_mfma(void* stream) {
     float *dA = nullptr, *dB = nullptr, *dD = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dA), 1024));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dB), 1024));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dD), 1024));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dD), 1536));
     HIP_TRY(hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dB, Bm.data(), 1024, hipMemcpyHostToDevice));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, st, dA, dB, dD);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(D.data(), dD, 1536, hipMemcpyDeviceToHost));
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
     int bad = 0;
     for (int i = 0; i < 256; ++i) bad += (D[i] != ref[i]);
     if (bad) return fail(VT_ERR_STATE, "MFMA lane map differs from the assumed one in " + std::to_string(bad) + " / 256 elements");
+    for (int l = 0; l < 64; ++l) bad += (D[256 + l] != 15.f * ((l & 15) + 1)) + (D[320 + l] != 8.f * ((l & 15) + 1));
+    if (bad) return fail(VT_ERR_STATE, "v_permlane16/32_swap lane map differs from the assumed one (" + std::to_string(bad) + " / 128)");
     return VT_OK;
 }
 

@@ -19,6 +19,7 @@
 // S^T = K q^T is computed with keys as rows, so a softmax row lives in one lane's registers plus
 // the 3 partner lanes (two xor-shuffles), never in LDS.
 #pragma once
+#include <type_traits>
 #include "vt_common.h"
 
 namespace vtb {
@@ -44,6 +45,32 @@ constexpr int O_W2 = O_B1 + HID;                   // 3 x 12 tiles
 constexpr int O_B2 = O_W2 + NC * NH * 256;
 constexpr int BLOCK_STRIDE = O_B2 + C;             // 28272 floats
 static_assert(BLOCK_STRIDE % 4 == 0 && O_WQKV % 4 == 0 && O_W1 % 4 == 0 && O_W2 % 4 == 0, "16B alignment");
+
+// The small parameters of a block (LayerNorm gamma / beta and the four bias vectors, 624 floats) are
+// copied to LDS once when the kernel starts.  Read from global memory where they are used -- as the
+// accumulator initialisers in front of a GEMM -- each one exposes an L2 round trip of several hundred
+// cycles with nothing to hide it behind; from LDS they cost what an operand image costs.
+constexpr int S_LN1G = 0;
+constexpr int S_LN1B = S_LN1G + C;
+constexpr int S_BQKV = S_LN1B + C;
+constexpr int S_BPROJ = S_BQKV + 3 * C;
+constexpr int S_LN2G = S_BPROJ + C;
+constexpr int S_LN2B = S_LN2G + C;
+constexpr int S_B1 = S_LN2B + C;
+constexpr int S_B2 = S_B1 + HID;
+constexpr int SMALL_STRIDE = S_B2 + C;             // 624 floats per block; the final norm (2 C) follows the last block
+static_assert(SMALL_STRIDE % 4 == 0 && S_BQKV % 4 == 0 && S_BPROJ % 4 == 0 && S_B1 % 4 == 0 && S_B2 % 4 == 0, "16B alignment");
+static_assert(O_LN1B == O_LN1G + C && O_LN2G == O_BPROJ + C && O_LN2B == O_LN2G + C, "contiguous sections");
+__host__ __device__ constexpr int small_floats(int depth) { return depth * SMALL_STRIDE + 2 * C; }
+
+// global offset (floats, relative to params) of small-parameter float `f` of the LDS copy
+__device__ __forceinline__ size_t small_src(int f, int depth) {
+    const int blk = f / SMALL_STRIDE, r = f - blk * SMALL_STRIDE;
+    if (blk >= depth) return (size_t)depth * BLOCK_STRIDE + r;    // norm.weight, norm.bias
+    const int o = r < S_BQKV ? O_LN1G + r : r < S_BPROJ ? O_BQKV + (r - S_BQKV) : r < S_B1 ? O_BPROJ + (r - S_BPROJ)
+                : r < S_B2 ? O_B1 + (r - S_B1) : O_B2 + (r - S_B2);
+    return (size_t)blk * BLOCK_STRIDE + o;
+}
 
 __device__ __forceinline__ f4 wimg(const float* __restrict__ base, int tile, int lane) {
     return ld4(base + (size_t)tile * 256 + lane * 4);
@@ -84,7 +111,7 @@ __device__ __forceinline__ void layer_norm_img(const f4 (&x)[NC], f4 (&h)[NC], c
         f4 d = x[c] - splat4(mean);
         v += hsum4(d * d);
     }
-    const float inv = 1.0f / sqrtf(quad_sum(v) * (1.0f / C) + LN_EPS);
+    const float inv = __builtin_amdgcn_rsqf(quad_sum(v) * (1.0f / C) + LN_EPS);   // v_rsq_f32: 1 ulp
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const f4 gg = ld4(g + 16 * c + 4 * q), bb = ld4(b + 16 * c + 4 * q);
@@ -143,32 +170,54 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
 
 // NT = token tiles per frame (L / 16), NW = waves per workgroup, TPW = tiles per wave.
 // (min waves per SIMD: the lean 5-wave variant is capped at 168 VGPRs so two or three workgroups share a CU)
-template <int NT, int NW, int TPW, bool WLDS>
+//
+// BAL (G128: 5 tiles on a CU's 4 SIMDs).  One wave per tile puts two tile-waves on SIMD0, which then
+// carries 2/5 of the MFMAs and sets the kernel time.  The balanced variant runs 8 waves: waves 0-3
+// ("owners", one per SIMD) own tiles 0-3 exactly as before; waves 4-7 ("guests", again one per SIMD)
+// share tile 4 four ways and keep its residual stream redundantly in registers:
+//     LN1 + QKV   guest 0: q -> Qg (LDS), guest 1: k -> Kimg, guest 2: v -> Vimg          (36 MFMAs each)
+//     attention   guest g: keys of tile g (guest 3: tiles 3 and 4) -> partial (max, sum, P.V) in LDS,
+//                 guests-only rendezvous on an LDS counter, flash-style merge               (24 / 48)
+//     proj        guest g < 3: output tile g -> Dg (LDS); every guest adds all three        (12)
+//     LN2 + fc1   guest g: hidden tiles 3g..3g+2, GELU                                      (36)
+//     fc2         K-split: guest g contracts its own hidden tiles -> partial in LDS; summed (36)
+// Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream
+// whose MFMAs fill the owner's LayerNorm / softmax / GELU sections.
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
 __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
                                                          float* __restrict__ resid,          // (B, L, C) or null
                                                          int len_z, int depth_total, int nblocks,
-                                                         int dbg_skip_tile,                  // timing experiments only (-1);
-                                                                                             // bits 8.. = ablation flags
+                                                         int dbg_skip_tile,                  // timing experiments only (-1)
                                                          unsigned long long* __restrict__ stamps) {   // diagnostic, null in production
     static_assert(NW * TPW >= NT, "tiles must be covered");
+    static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
     constexpr int L = NT * 16;
+    constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
+    constexpr int GT = NT - 1;                             // BAL: the guests' tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]
     f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
     f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
     f4* Wb = Wa + WBUF_TILES * 64;                         // WLDS: [36][64] staging buffer B
+    float* Sp = reinterpret_cast<float*>(WLDS ? Wb + WBUF_TILES * 64 : Wa);   // small parameters, small_floats(depth)
+    // BAL: guest exchange areas
+    f4* Qg = reinterpret_cast<f4*>(Sp + small_floats(depth_total));   // [NC][64]      q of the guest tile
+    f4* Pg = Qg + NC * 64;                                            // [4][NC][64]   attention / fc2 partials
+    f4* Dg = Pg + 4 * NC * 64;                                        // [NC][64]      proj output tiles
+    float* Mg = reinterpret_cast<float*>(Dg + NC * 64);               // [4][2][64]    partial softmax max / sum
+    int* gflag = reinterpret_cast<int*>(Mg + 4 * 2 * 64);             // guests' rendezvous counter
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tok = lane & 15, q = lane >> 4;
+    const int g = w - (NT - 1);                            // BAL: guest index of waves >= NT-1
     const float scale = 0.14433756729740643f;  // 48^-0.5  (head_dim ** -0.5, attn.py:15)
-    // timing ablations (wrong results by design): 1 = GELU -> identity, 2 = exp -> identity, 4 = no MFMA in the MLP
-    const int ablate = dbg_skip_tile >= 256 ? (dbg_skip_tile >> 8) : 0;
-    if (dbg_skip_tile >= 256) dbg_skip_tile = (dbg_skip_tile & 255) == 255 ? -1 : (dbg_skip_tile & 255);
-
+    const int guest_prio = dbg_skip_tile == -3 ? 0 : 1;   // -3: experiment, guests at default priority
+    const bool fine = dbg_skip_tile == -2 || dbg_skip_tile <= -100;          // -2: per-stage stamps; -(100 + t): per-stage stamps and tile t skipped
+    if (dbg_skip_tile <= -100) dbg_skip_tile = -100 - dbg_skip_tile;
     // diagnostic phase stamps: shader-clock reads by lane 0 of every wave, [b][w][64]
     int nstamp = 0;
     auto stamp = [&]() {
@@ -179,23 +228,39 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             ++nstamp;
         }
     };
+    auto fstamp = [&]() { if (fine) stamp(); };     // per-stage stamps (VT_DBG_STAMPS=2)
     stamp();
     if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
+    for (int i = threadIdx.x; 4 * i < small_floats(depth_total); i += NW * 64)
+        st4(Sp + 4 * i, ld4(params + small_src(4 * i, depth_total)));
 
     f4 x[TPW][NC];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int T = w + NW * i;
-        if (T < NT && T != dbg_skip_tile) {
+        if (T < NOWN && T != dbg_skip_tile) {
             const float* src = tokens + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
 #pragma unroll
             for (int c = 0; c < NC; ++c) x[i][c] = ld4(src + 16 * c);
         }
     }
-    if constexpr (WLDS) __syncthreads();
+    f4 x4[NC];                                   // BAL: every guest's copy of the guest tile's residual stream
+    if constexpr (BAL) {
+        if (w >= NOWN) {
+            const float* src = tokens + ((size_t)b * L + 16 * GT + tok) * C + 4 * q;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x4[c] = ld4(src + 16 * c);
+        }
+        if (threadIdx.x == 0) *gflag = 0;
+        // the guests' short chains sit on every phase's critical path (the owners wait for them at the
+        // barriers), but the issue arbiter favours the older owner waves: raise the guests' priority
+        if (w >= NOWN && guest_prio > 0) __builtin_amdgcn_s_setprio(2);
+    }
+    __syncthreads();
 
     for (int blk = 0; blk < nblocks; ++blk) {
         const float* __restrict__ P = params + (size_t)blk * BLOCK_STRIDE;
+        const float* S = Sp + blk * SMALL_STRIDE;
         // weight operand image `t` of each GEMM: from the staging buffers (WLDS) or straight from L2
         auto w_qkv = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_WQKV, t, lane); };
         auto w_proj = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_WPROJ, t, lane); };
@@ -208,13 +273,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT && T != dbg_skip_tile) {
+            if (T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
-                layer_norm_img(x[i], h, P + O_LN1G, P + O_LN1B, q);
+                layer_norm_img(x[i], h, S + S_LN1G, S + S_LN1B, q);
+                fstamp();
                 {   // q and k: 6 independent chains, rows = features, cols = tokens (B = h shared)
                     f4 acc[2 * NC];
 #pragma unroll
-                    for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(P + O_BQKV + 16 * ot + 4 * q);
+                    for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(S + S_BQKV + 16 * ot + 4 * q);
                     gemm_stage<NC, 2 * NC, true, WLDS>(
                         [&](int c, f4 (&a)[2 * NC]) {
 #pragma unroll
@@ -227,10 +293,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         Kimg[(T * NC + ot) * 64 + lane] = acc[NC + ot];
                     }
                 }
+                fstamp();
                 {   // v, operands swapped: rows = tokens, cols = v features (A = h shared) -> V^T image
                     f4 acc[NC];
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
+                    for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
                     gemm_stage<NC, NC, false, WLDS>(
                         [&](int c, f4 (&bw)[NC]) {
 #pragma unroll
@@ -239,6 +306,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         [&](int c) { return h[c]; }, acc);
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
+                }
+            }
+        }
+        if constexpr (BAL) {
+            if (w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
+                f4 h[NC];
+                layer_norm_img(x4, h, S + S_LN1G, S + S_LN1B, q);
+                f4 acc[NC];
+                if (g < 2) {
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) acc[ot] = ld4(S + S_BQKV + 16 * (g * NC + ot) + 4 * q);
+                    gemm_stage<NC, NC, true, true>(
+                        [&](int c, f4 (&a)[NC]) {
+#pragma unroll
+                            for (int ot = 0; ot < NC; ++ot) a[ot] = w_qkv((g * NC + ot) * NC + c);
+                        },
+                        [&](int c) { return h[c]; }, acc);
+                    f4* dst = g == 0 ? Qg : Kimg + GT * NC * 64;
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) dst[ot * 64 + lane] = acc[ot];
+                } else {
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
+                    gemm_stage<NC, NC, false, true>(
+                        [&](int c, f4 (&bw)[NC]) {
+#pragma unroll
+                            for (int ot = 0; ot < NC; ++ot) bw[ot] = w_qkv((2 * NC + ot) * NC + c);
+                        },
+                        [&](int c) { return h[c]; }, acc);
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + GT) * 64 + lane] = acc[ot];
                 }
             }
         }
@@ -254,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+            if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                 f4 s[NT];
                 float m = -3.0e38f;
                 constexpr int JG = 5;                    // key tiles per group = independent chains
@@ -277,20 +375,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         m = fmaxf(m, hmax4(acc[j]));
                     }
                 }
+                fstamp();
                 m = quad_max(m);
                 float den = 0.f;
 #pragma unroll
                 for (int J = 0; J < NT; ++J) {
                     f4 e;
-                    if (ablate & 2) e = s[J] - splat4(m);
-                    else {
-                        e.x = __expf(s[J].x - m); e.y = __expf(s[J].y - m);
-                        e.z = __expf(s[J].z - m); e.w = __expf(s[J].w - m);
-                    }
+                    e.x = __expf(s[J].x - m); e.y = __expf(s[J].y - m);
+                    e.z = __expf(s[J].z - m); e.w = __expf(s[J].w - m);
                     s[J] = e;
                     den += hsum4(e);
                 }
-                const float rden = 1.0f / quad_sum(den);
+                const float rden = __builtin_amdgcn_rcpf(quad_sum(den));     // v_rcp_f32: 1 ulp
+                fstamp();
                 f4 o[NC];
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
@@ -302,14 +399,101 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     [&](int J) { return s[J]; }, o);
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
+                fstamp();
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_BPROJ + 16 * ot + 4 * q);
+                for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q);
                 gemm_stage<NC, NC, true, WLDS>(
                     [&](int c, f4 (&a)[NC]) {
 #pragma unroll
                         for (int ot = 0; ot < NC; ++ot) a[ot] = w_proj(ot * NC + c);
                     },
                     [&](int c) { return o[c]; }, x[i]);
+            }
+        }
+        if constexpr (BAL) {
+            if (w >= NOWN) {
+                // partial attention of the guest queries over this guest's key tiles
+                auto attn_part = [&](auto njc, int J0) {
+                    constexpr int NJ = decltype(njc)::value;
+                    f4 qv[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) qv[c] = Qg[c * 64 + lane];
+                    f4 sc[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) sc[j] = splat4(0.f);
+                    gemm_stage<NC, NJ, true, true>(
+                        [&](int c, f4 (&a)[NJ]) {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j) a[j] = Kimg[((J0 + j) * NC + c) * 64 + lane];
+                        },
+                        [&](int c) { return qv[c]; }, sc);
+                    float m = -3.0e38f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        sc[j] = sc[j] * splat4(scale);
+                        m = fmaxf(m, hmax4(sc[j]));
+                    }
+                    m = quad_max(m);
+                    float den = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        f4 e;
+                        e.x = __expf(sc[j].x - m); e.y = __expf(sc[j].y - m);
+                        e.z = __expf(sc[j].z - m); e.w = __expf(sc[j].w - m);
+                        sc[j] = e;
+                        den += hsum4(e);
+                    }
+                    den = quad_sum(den);
+                    f4 o[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
+                    gemm_stage<NJ, NC, true, true>(
+                        [&](int J, f4 (&a)[NC]) {
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J0 + J) * 64 + lane];
+                        },
+                        [&](int J) { return sc[J]; }, o);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) Pg[(g * NC + t) * 64 + lane] = o[t];
+                    Mg[(g * 2 + 0) * 64 + lane] = m;
+                    Mg[(g * 2 + 1) * 64 + lane] = den;
+                };
+                if (g == 3) attn_part(std::integral_constant<int, NT - 3>{}, 3);
+                else attn_part(std::integral_constant<int, 1>{}, g);
+                // guests-only rendezvous: every guest has published its partial
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (g < 3) {
+                    while (__hip_atomic_load(gflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (blk + 1))
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    // merge the four partial softmaxes; output tile g of proj
+                    float mk[4], lk[4], M = -3.0e38f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        mk[k] = Mg[(k * 2 + 0) * 64 + lane];
+                        lk[k] = Mg[(k * 2 + 1) * 64 + lane];
+                        M = fmaxf(M, mk[k]);
+                    }
+                    float Lsum = 0.f;
+                    f4 o[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float f = __expf(mk[k] - M);
+                        Lsum = fmaf(f, lk[k], Lsum);
+#pragma unroll
+                        for (int t = 0; t < NC; ++t) o[t] = o[t] + splat4(f) * Pg[(k * NC + t) * 64 + lane];
+                    }
+                    const float rl = __builtin_amdgcn_rcpf(Lsum);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rl);
+                    f4 acc[1] = {splat4(0.f)};
+                    gemm_stage<NC, 1, true, true>([&](int c, f4 (&a)[1]) { a[0] = w_proj(g * NC + c); },
+                                                  [&](int c) { return o[c]; }, acc);
+                    Dg[g * 64 + lane] = acc[0];
+                }
             }
         }
         stamp();            // attention + proj done
@@ -327,7 +511,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         f4 acc2[NHID][HG];
         auto fc1 = [&](const f4 (&h)[NC], int g, f4 (&acc)[HG]) {
 #pragma unroll
-            for (int j = 0; j < HG; ++j) acc[j] = ld4(P + O_B1 + 16 * (HG * g + j) + 4 * q);
+            for (int j = 0; j < HG; ++j) acc[j] = ld4(S + S_B1 + 16 * (HG * g + j) + 4 * q);
             gemm_stage<NC, HG, true, WLDS>(
                 [&](int c, f4 (&a)[HG]) {
 #pragma unroll
@@ -338,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         auto gelu_group = [&](const f4 (&acc)[HG], f4 (&hd)[NH], int g) {
 #pragma unroll
             for (int j = 0; j < HG; ++j)
-                hd[HG * g + j] = (ablate & 1) ? acc[j] : f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
+                hd[HG * g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
         };
         auto fc2 = [&](const f4 (&hd)[NH], int g, f4 (&xo)[NC]) {
             gemm_stage<HG, NC, true, WLDS>(
@@ -350,16 +534,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         };
         auto mlp_first = [&](int i, int hi) {          // LN2, fc1 (all groups), GELU of groups 0 and 1
             f4 h[NC];
-            layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
+            layer_norm_img(x[i], h, S + S_LN2G, S + S_LN2B, q);
 #pragma unroll
-            for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
+            for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
             f4 acc0[HG], acc1[HG];
+            fstamp();
             fc1(h, 0, acc0);
             __builtin_amdgcn_sched_barrier(0);
+            fstamp();
             fc1(h, 1, acc1);
             gelu_group(acc0, hid[hi], 0);
             interleave_mfma_valu<12 * HG, 5>();
             __builtin_amdgcn_sched_barrier(0);
+            fstamp();
             fc1(h, 2, acc2[hi]);
             gelu_group(acc1, hid[hi], 1);
             interleave_mfma_valu<12 * HG, 5>();
@@ -370,14 +557,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             gelu_group(acc2[hi], hid[hi], 2);
             interleave_mfma_valu<12 * HG, 5>();
             __builtin_amdgcn_sched_barrier(0);
+            fstamp();
             fc2(hid[hi], 1, x[i]);
+            fstamp();
             fc2(hid[hi], 2, x[i]);
         };
         if constexpr (WLDS) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first(i, i);
+                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first(i, i);
+            }
+            f4 ghid[NC];        // BAL: GELU(fc1) of this guest's three hidden tiles
+            if constexpr (BAL) {
+                if (w >= NOWN) {
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q) + Dg[ot * 64 + lane];
+                    f4 h[NC];
+                    layer_norm_img(x4, h, S + S_LN2G, S + S_LN2B, q);
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) ghid[j] = ld4(S + S_B1 + 16 * (NC * g + j) + 4 * q);
+                    gemm_stage<NC, NC, true, true>(
+                        [&](int c, f4 (&a)[NC]) {
+#pragma unroll
+                            for (int j = 0; j < NC; ++j) a[j] = w_fc1((NC * g + j) * NC + c);
+                        },
+                        [&](int c) { return h[c]; }, ghid);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j)
+                        ghid[j] = f4{gelu_erf(ghid[j].x), gelu_erf(ghid[j].y), gelu_erf(ghid[j].z), gelu_erf(ghid[j].w)};
+                }
             }
             stamp();            // fc1 done
             __syncthreads();    // fc2 weights landed; buffer A free
@@ -386,7 +597,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second(i, i);
+                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second(i, i);
+            }
+            if constexpr (BAL) {
+                if (w >= NOWN) {   // fc2 restricted to this guest's hidden tiles: a partial sum of the update
+                    f4 part[NC];
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
+                    gemm_stage<NC, NC, true, true>(
+                        [&](int cc, f4 (&a)[NC]) {
+#pragma unroll
+                            for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + NC * g + cc);
+                        },
+                        [&](int cc) { return ghid[cc]; }, part);
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) Pg[(g * NC + ot) * 64 + lane] = part[ot];
+                }
             }
         } else {
             // many tiles per wave (G256): plain per-tile MLP in two groups of 6 hidden tiles -- the
@@ -396,14 +622,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 const int T = w + NW * i;
                 if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                     f4 h[NC];
-                    layer_norm_img(x[i], h, P + O_LN2G, P + O_LN2B, q);
+                    layer_norm_img(x[i], h, S + S_LN2G, S + S_LN2B, q);
                     f4 hd[NH];
                     constexpr int G6 = 6;
 #pragma unroll
                     for (int g = 0; g < NH; g += G6) {
                         f4 acc[G6];
 #pragma unroll
-                        for (int j = 0; j < G6; ++j) acc[j] = ld4(P + O_B1 + 16 * (g + j) + 4 * q);
+                        for (int j = 0; j < G6; ++j) acc[j] = ld4(S + S_B1 + 16 * (g + j) + 4 * q);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
                             f4 a[G6];
@@ -416,7 +642,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                             hd[g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
                     }
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
+                    for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
 #pragma unroll
                     for (int c = 0; c < NH; ++c) {
                         f4 a[NC];
@@ -429,16 +655,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         }
         stamp();            // MLP done
         if constexpr (WLDS) __syncthreads();   // buffer B free; next qkv weights landed
+        if constexpr (BAL) {
+            if (w >= NOWN) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + Pg[(k * NC + ot) * 64 + lane];
+            }
+        }
     }
 
     stamp();
     // ---- epilogue: optional residual dump; final LayerNorm on the search tokens ----------------
-    const float* __restrict__ PF = params + (size_t)depth_total * BLOCK_STRIDE;   // norm.weight, norm.bias
+    const float* PF = Sp + depth_total * SMALL_STRIDE;   // norm.weight, norm.bias
     const int Lx = L - len_z;
+    if constexpr (BAL) {
+        if (g == 0) {
+            if (resid != nullptr) {
+                float* dst = resid + ((size_t)b * L + 16 * GT + tok) * C + 4 * q;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) st4(dst + 16 * c, x4[c]);
+            }
+            f4 h[NC];
+            layer_norm_img(x4, h, PF, PF + C, q);
+            float* dst = feat + ((size_t)b * Lx + (16 * GT - len_z) + tok) * C + 4 * q;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) st4(dst + 16 * c, h[c]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int T = w + NW * i;
-        if (T < NT) {
+        if (T < NOWN) {
             if (resid != nullptr) {
                 float* dst = resid + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
 #pragma unroll

@@ -46,15 +46,33 @@ __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<con
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 
 // Sum / max over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of one register
+// with the even rows (lower half) of another; fed the same value twice they return {v[l & ~16],
+// v[l | 16]} (resp. 32): the two xor partners, in VALU latency instead of two ds_bpermute round
+// trips through the LDS queue.  vt_selftest_mfma checks this lane map.
+__device__ __forceinline__ void xor_pair16(float v, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void xor_pair32(float v, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    float a, b;
+    xor_pair16(v, a, b);
+    v = a + b;
+    xor_pair32(v, a, b);
+    return a + b;
 }
 __device__ __forceinline__ float quad_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    float a, b;
+    xor_pair16(v, a, b);
+    v = fmaxf(a, b);
+    xor_pair32(v, a, b);
+    return fmaxf(a, b);
 }
 
 __device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
