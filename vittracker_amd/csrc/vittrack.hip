@@ -18,6 +18,7 @@
 #include "vt_blocks.h"
 #include "vt_head.h"
 #include "vt_stem.h"
+#include "vt_stem_fused.h"
 #include "vt_track.h"
 
 namespace {
@@ -75,6 +76,8 @@ struct vt_model {
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
     int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
+    int stem_fused = 1;    // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b
+    int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
     int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
@@ -242,10 +245,29 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
             3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64)
             return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
     }
+    if (m->stem_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
+        // whole patch embedding of a frame in one workgroup; only token rows leave the CU
+        hipLaunchKernelGGL(vts::stem_fused_kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p,
+                           m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p,
+                           m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps);
+        HIP_TRY(hipGetLastError());
+        return VT_OK;
+    }
     vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
-    const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
-    hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
-                       m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
+    // fused form: band k of both crops in one workgroup, when the template band then has exactly one
+    // layer-2 tile per wave and the workgroup count fills whole rounds of 4 per CU better than the split form
+    const int r2z_f = (Tz / 4) / ax.bands;
+    const bool fuse = m->stem_fuse && r2z_f >= 1 && r2z_f * ax.bands == Tz / 4 && r2z_f * (Tz / 4) == 64;
+    if (fuse) {
+        az.r2 = r2z_f; az.bands = ax.bands;
+        const size_t lds_a = sizeof(float) * (vts::stem_a_lds_floats(Tx, ax.r2) + vts::stem_a_lds_floats(Tz, az.r2));
+        hipLaunchKernelGGL(vts::stem_a2_kernel, dim3(B * ax.bands), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
+                           m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
+    } else {
+        const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
+        hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
+                           m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
+    }
     HIP_TRY(hipGetLastError());
     vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
     vts::CropB bz{act_z, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
@@ -401,6 +423,8 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
+    m->stem_fused = env_int("VT_STEM_FUSED", 1);
+    m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
@@ -420,11 +444,21 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     if (!rc) {
         // > 64 KiB of dynamic LDS needs an explicit opt-in
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16 + 16384);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 5, 1, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16);
+                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16 + 16384);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16 + 16384);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16 + 49152);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_fused_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, vts::FusedGeo::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,

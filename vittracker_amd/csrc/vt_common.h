@@ -44,6 +44,8 @@ __device__ __forceinline__ f4 splat4(float v) { return f4{v, v, v, v}; }
 
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+// streaming store: the line is not kept dirty in this XCD's L2 until the end-of-kernel write-back
+__device__ __forceinline__ void st4_nt(float* p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p)); }
 
 // Sum / max over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48.
 // gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of one register

@@ -46,7 +46,8 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wimg, int
 // MFMA costs a basic block + register shuffling per instruction and halves the pipe's duty).
 //   base[i]  per-lane map offset of tap (0,0) for pixel tile i
 //   off(c)   per-lane map offset of this lane's quad of chunk c (tap + channel-quad part)
-template <int NOT, int NPT, int MAXC, int N, typename OffFn>
+// PIN: keep the next chunk's B reads ahead of this chunk's MFMAs (see below); costs registers, so opt-in.
+template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename OffFn>
 __device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT], const f4 (&a)[MAXC][NOT], int c0,
                                          OffFn off, f4 (&acc)[NPT][NOT]) {
     static_assert(N <= MAXC, "chunk count");
@@ -62,6 +63,9 @@ __device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT
             const int o = off(c0 + k + 1);
 #pragma unroll
             for (int i = 0; i < NPT; ++i) b[(k + 1) & 1][i] = in_map[o + base[i]];
+            // keep these reads ahead of chunk k's MFMAs: left alone, the scheduler sinks them to just before
+            // their first use and every chunk then starts with a full LDS round trip
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)

@@ -106,8 +106,8 @@ struct HeadConv {
             constexpr int LASTN = NCH - (NPASS - 1) * MAXC;
             if (p + 1 < NPASS)
                 vtc::load_weights<1, MAXC, NCH>(wb, (p + 1) * MAXC, p + 2 < NPASS ? MAXC : LASTN, lane, a[(p + 1) & 1]);
-            if (p + 1 < NPASS) vtc::mma_pass<1, NPT, MAXC, MAXC>(in_map, base, a[p & 1], p * MAXC, off, acc);
-            else vtc::mma_pass<1, NPT, MAXC, LASTN>(in_map, base, a[p & 1], p * MAXC, off, acc);
+            if (p + 1 < NPASS) vtc::mma_pass<1, NPT, MAXC, MAXC, true>(in_map, base, a[p & 1], p * MAXC, off, acc);
+            else vtc::mma_pass<1, NPT, MAXC, LASTN, true>(in_map, base, a[p & 1], p * MAXC, off, acc);
         }
         if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
 #pragma unroll

@@ -56,7 +56,7 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
 struct CropA {            // one crop for stem_a
     const float* in;      // (B, 3, T, T) NCHW
-    float* out;           // (B, T/4, T/4, 12) NHWC
+    float* out;           // (B, 3, T/4, T/4, 4): layer-2 map as three channel-quad planes
     int T;                // crop side
     int r2;               // layer-2 rows per band
     int bands;            // (T/4) / r2
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
         map1[(i / NR1) * npix1 + (i % NR1) * PITCH + HALF] = splat4(0.f);
     __syncthreads();
 
-    // ---- layer 2 (6 -> 12, MFMA implicit GEMM) -> NHWC(12) in global memory -----------------------
+    // ---- layer 2 (6 -> 12, MFMA implicit GEMM) -> quad planes in global memory --------------------
     const int w2_log2 = ilog2(W2);
     const int q = lane >> 4, px = lane & 15;
     auto store2 = [&](int t, int ot, f4 v) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
             const int op = 16 * t + px;
             const int y = op >> w2_log2, x = op - (y << w2_log2);
             v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
-            st4(out + (((size_t)b * W2 + p0 + y) * W2 + x) * 12 + 4 * q, v);
+            st4(out + ((((size_t)b * 3 + q) * W2 + p0 + y) * W2 + x) * 4, v);     // quad plane q: 16 lanes = 256 contiguous bytes
         }
     };
     if (!(skip & 2)) {
@@ -211,9 +211,162 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------- stem_a, fused crops
+// Same arithmetic as stem_a_kernel, but one workgroup handles band k of the search crop AND band k
+// of the template crop (the crops must have the same number of bands).  At G128 that turns 5
+// workgroups per frame into 4: 1024 for a batch of 256, i.e. exactly one resident round on 256 CUs
+// x 4 workgroups (the 5-per-frame form needs a second round that is only a quarter full).
+// Layer-1 work is dealt to the waves in wave-uniform units of 64 pixel pairs (x units first, then z),
+// so every per-crop quantity is a scalar; all sizes are powers of two, so index arithmetic is shifts,
+// and a load address is a scalar plane pointer plus one 32-bit per-thread offset.
+struct JobA {
+    const float* in;      // this frame's crop, (3, T, T)
+    float* out;           // this frame's layer-2 map, (3, T/4, T/4, 4)
+    int map_off;          // f4 offset of this crop's layer-1 map in LDS
+    int T, lgT, HALF, lgHALF, PITCH, NR1, p0, npairs, npix1, R2, lgW2;
+};
+__device__ __forceinline__ JobA make_job_a(const CropA& c, int b, int k, int map_off) {
+    JobA j;
+    j.T = c.T; j.lgT = ilog2(c.T); j.HALF = c.T >> 2; j.lgHALF = j.lgT - 2; j.PITCH = (c.T >> 1) + 1;
+    j.R2 = c.r2; j.NR1 = 2 * c.r2 + 1; j.p0 = k * c.r2; j.npairs = j.NR1 * j.HALF; j.npix1 = stem_a_npix1(c.T, c.r2);
+    j.lgW2 = j.lgT - 2; j.map_off = map_off;
+    j.in = c.in + (size_t)b * 3 * c.T * c.T;
+    j.out = c.out + (size_t)b * (c.T >> 2) * (c.T >> 2) * 12;
+    return j;
+}
+// value of the previous lane (lane 0: 0) in VALU latency: v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ float lane_left(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a2_kernel(
+    CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
+    const float* __restrict__ w2img, const float* __restrict__ b2, int skip) {
+    extern __shared__ __attribute__((aligned(16))) float lds_a[];
+    f4* maps = reinterpret_cast<f4*>(lds_a);
+    const int bands = cx.bands;                   // == cz.bands (host check)
+    const int b = blockIdx.x / bands, k = blockIdx.x - b * bands;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const JobA jx = make_job_a(cx, b, k, 0);
+    const JobA jz = make_job_a(cz, b, k, 2 * jx.npix1);
+    const int ux = (jx.npairs + 63) >> 6, nu = ux + ((jz.npairs + 63) >> 6);
+
+    // ---- layer 1 (3 -> 6, VALU) ---------------------------------------------------------------------
+    auto fetch = [&](const JobA& J, int i, f4 (&v)[3][3]) {
+        i = i < J.npairs ? i : J.npairs - 1;        // clamped lanes recompute the last pair
+        const int lr = i >> J.lgHALF, qp = i & (J.HALF - 1);
+        const int p1 = 2 * J.p0 - 1 + lr;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int iy = 2 * p1 + r - 1;                // < 0 only at the image top: zeroed, branch-free
+            const float keep = iy >= 0 ? 1.f : 0.f;
+            iy = iy >= 0 ? iy : 0;
+            const unsigned off = ((unsigned)iy << J.lgT) + 4u * (unsigned)qp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off) * splat4(keep);
+        }
+    };
+    auto compute = [&](const JobA& J, int i, const f4 (&v)[3][3]) {
+        const bool in_range = i < J.npairs;
+        i = in_range ? i : J.npairs - 1;
+        const int lr = i >> J.lgHALF, qp = i & (J.HALF - 1);
+        const int p1 = 2 * J.p0 - 1 + lr;
+        float a0[6], a1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+        float wa[18], wb[18];
+        load_section(wa, w1g, 0);
+#pragma unroll
+        for (int sec = 0; sec < 9; ++sec) {
+            float (&cur)[18] = (sec & 1) ? wb : wa;
+            float (&nxt)[18] = (sec & 1) ? wa : wb;
+            if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
+            const int r = sec / 3, c = sec % 3;
+            // column 4*qp-1 is the previous lane's .w (a unit starts at a row start, so lane 0 has qp = 0)
+            const float left = lane_left(v[r][c].w);
+            const float t0[3] = {qp > 0 ? left : 0.f, v[r][c].x, v[r][c].y}, t1[3] = {v[r][c].y, v[r][c].z, v[r][c].w};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
+                    a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
+                }
+        }
+        const float live = p1 < 0 ? 0.f : 1.f;      // row -1 of the layer-1 map = layer 2's zero padding
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]) * live; a1[j] = hardswish(a1[j]) * live; }
+        if (in_range) {
+            f4* dst = maps + J.map_off + lr * J.PITCH;
+            dst[qp] = f4{a0[0], a0[1], a0[2], a0[3]};
+            dst[J.npix1 + qp] = f4{a0[4], a0[5], 0.f, 0.f};
+            dst[J.HALF + 1 + qp] = f4{a1[0], a1[1], a1[2], a1[3]};
+            dst[J.npix1 + J.HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
+        }
+    };
+    if (!(skip & 1)) {
+        f4 va[3][3], vb[3][3];
+        if (wave < nu) fetch(wave < ux ? jx : jz, ((wave < ux ? wave : wave - ux) << 6) + lane, va);
+        for (int u = wave; u < nu; u += 4) {
+            const int un = u + 4;
+            if (un < nu) fetch(un < ux ? jx : jz, ((un < ux ? un : un - ux) << 6) + lane, vb);   // next unit in flight
+            compute(u < ux ? jx : jz, ((u < ux ? u : u - ux) << 6) + lane, va);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) va[r][c] = vb[r][c];
+        }
+    }
+    f4 w2a[5][1];                                // layer-2 weights: in flight across the barrier below
+    vtc::load_weights<1, 5, 5>(w2img, 0, 5, lane, w2a);
+    for (int i = threadIdx.x; i < 2 * (jx.NR1 + jz.NR1); i += 256) {     // column -1 of every row of both maps
+        const bool zz = i >= 2 * jx.NR1;
+        const int ii = zz ? i - 2 * jx.NR1 : i;
+        const int nr = zz ? jz.NR1 : jx.NR1, npx = zz ? jz.npix1 : jx.npix1, pt = zz ? jz.PITCH : jx.PITCH;
+        const int plane = ii >= nr ? 1 : 0, row = ii - plane * nr;
+        maps[(zz ? jz.map_off : 0) + plane * npx + row * pt + (zz ? jz.HALF : jx.HALF)] = splat4(0.f);
+    }
+    __syncthreads();
+
+    // ---- layer 2 (6 -> 12, MFMA implicit GEMM) -> quad planes in global memory --------------------
+    if (!(skip & 2)) {
+        const int q = lane >> 4, px = lane & 15;
+        const f4 bv = ld4(b2 + 4 * q);
+        auto run2 = [&](const JobA& J, auto npt_c, int t0, int tstride) {
+            constexpr int NPT = decltype(npt_c)::value;
+            int base[NPT];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int op = 16 * (t0 + tstride * i) + px;
+                const int y = op >> J.lgW2, x = op & ((1 << J.lgW2) - 1);
+                base[i] = 2 * y * J.PITCH + x;
+            }
+            f4 acc[NPT][1];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) acc[i][0] = bv;
+            auto off2 = [&](int c) { return s2_chunk_off<2>(c, q, J.npix1, J.PITCH, J.HALF); };
+            if (!(skip & 8)) vtc::mma_pass<1, NPT, 5, 5>(maps + J.map_off, base, w2a, 0, off2, acc);
+            if (q < 3 && !(skip & 4)) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const int op = 16 * (t0 + tstride * i) + px;
+                    const int y = op >> J.lgW2, x = op & ((1 << J.lgW2) - 1);
+                    f4 v = acc[i][0];
+                    v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
+                    st4(J.out + ((((size_t)q << (2 * J.lgW2)) + (((size_t)J.p0 + y) << J.lgW2) + x) << 2), v);   // quad plane q
+                }
+            }
+        };
+        const int ntx = (jx.R2 << jx.lgW2) >> 4;             // multiple of 16 (host check)
+        for (int t0 = wave; t0 < ntx; t0 += 16) run2(jx, std::integral_constant<int, 4>{}, t0, 4);
+        run2(jz, std::integral_constant<int, 1>{}, wave, 0);  // the template band: 4 tiles, one per wave (host check)
+    }
+}
+
 // ------------------------------------------------------------------------------------------ stem_b
 struct CropB {
-    const float* in;      // (B, S2, S2, 12) NHWC, S2 = T/4
+    const float* in;      // (B, 3, S2, S2, 4) quad planes, S2 = T/4
     const float* pos;     // (S4*S4, 48)
     int S2;               // layer-2 map side
     int r4;               // token rows per band
@@ -276,11 +429,11 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
     // layer-2 activations of the band -> map2 (rows outside the image stay zero)
     if (!(skip & 2))
     for (int i = threadIdx.x; i < NR2 * S2 * 3; i += 256) {
-        const int icq = i % 3, pc = i / 3;
+        const int icq = i / (NR2 * S2), pc = i - icq * (NR2 * S2);
         const int lr = pc / S2, col = pc - lr * S2;
         const int r2 = r2_0 + lr;
         if (r2 >= 0 && r2 < S2) {
-            const f4 v = ld4(in + (((size_t)b * S2 + r2) * S2 + col) * 12 + 4 * icq);
+            const f4 v = ld4(in + ((((size_t)b * 3 + icq) * S2 + r2) * S2 + col) * 4);
             map2[icq * npix2 + lr * pitch2 + ((col & 1) ? half2 + 1 + (col >> 1) : (col >> 1))] = v;
         }
     }

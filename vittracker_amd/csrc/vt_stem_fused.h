@@ -1,0 +1,342 @@
+// vt_stem_fused.h -- the whole patch embedding of one frame in one workgroup (G128: 128 / 64 px crops).
+//
+// Same arithmetic as stem_a + stem_b (vt_stem.h; reference: Conv2d_BN / b16 / LevitPatchEmbedding and
+// the pos-embed add + cat of OstrackDist.forward, lib/models/vit_dist/vit_dist.py:10-54,78-84), but
+// nothing except the token rows leaves the CU: the layer-2 and layer-3 maps of both crops stay in LDS
+// (139 KB), so the 15.7 MB intermediate, its end-of-kernel write-back, the second launch and its
+// re-read disappear.
+//
+// Why the wave groups: a wave never overlaps its own VALU work with its own MFMAs
+// (tools/src/probe_coissue.hip), and workgroups launched together run their phases in lock step, so
+// in the two-kernel form the VALU layer and the MFMA layer simply added up.  Here the 16 waves form
+// two groups of 8 (two waves per SIMD each) that work half a period apart:
+//
+//   interval      0        1        2        3        4        5
+//   group A    L1(z)    L2(z)    L1(x1)   L2(x1)   L1(x3)   L2(x3)
+//   group B   (fetch)   L1(x0)   L2(x0)   L1(x2)   L2(x2)     -
+//
+// L1 = layer 1 (3 -> 6, VALU, reads the crop from HBM; 512 pixel pairs = one per thread) into the
+// group's own LDS ring; L2 = layer 2 (6 -> 12, MFMA) from that ring into the frame's layer-2 map.
+// While one group's VALU pipe work runs, the other group's MFMAs use the matrix pipe of the same
+// SIMDs.  A band's input is fetched one interval ahead (during the group's L2), so HBM latency is
+// exposed once per frame.  A band's top halo row is the previous band's last row, copied from the
+// other group's ring (stable while that group is in its L2 interval).  Then all 16 waves run layer 3
+// (12 -> 24) and layer 4 (24 -> 48) + pos-embed as in stem_b, on whole maps.
+#pragma once
+#include <type_traits>
+
+#include "vt_common.h"
+#include "vt_conv.h"
+#include "vt_stem.h"
+
+namespace vts {
+
+struct FusedGeo {                       // TX = 128, TZ = 64
+    static constexpr int TX = 128, TZ = 64;
+    static constexpr int R2X = 8, NBX = (TX / 4) / R2X;            // 4 search bands of 8 layer-2 rows
+    static constexpr int R2Z = TZ / 4;                              // the template crop is one band of 16 rows
+    // layer-1 ring (one per group): [2 planes][2 R2 + 1 rows][T/2 + 1]
+    static constexpr int NPIX1X = round16((2 * R2X + 1) * (TX / 2 + 1));   // 1120
+    static constexpr int NPIX1Z = round16((2 * R2Z + 1) * (TZ / 2 + 1));   // 1104
+    static constexpr int RING = 2 * (NPIX1X > NPIX1Z ? NPIX1X : NPIX1Z);   // f4 per ring
+    // layer-2 maps: [3 planes][S2 + 1 rows][S2 + 1], parity-split columns (stem_b's map2 layout)
+    static constexpr int NPIX2X = round16((TX / 4 + 1) * (TX / 4 + 1));    // 1104
+    static constexpr int NPIX2Z = round16((TZ / 4 + 1) * (TZ / 4 + 1));    // 304
+    // layer-3 maps: [6 planes][S3 + 1 rows][S3 + 1] (stem_b's map3 layout); they reuse the rings
+    static constexpr int NPIX3X = round16((TX / 8 + 1) * (TX / 8 + 1));    // 304
+    static constexpr int NPIX3Z = round16((TZ / 8 + 1) * (TZ / 8 + 1));    // 96
+    // small constants, copied once: layer-2 weight images (5 x 64 f4), b2 (4 f4), b3 (8 f4), b4 (12 f4)
+    static constexpr int CONST_F4 = 5 * 64 + 4 + 8 + 12;
+    static constexpr int LDS_F4 = 2 * RING + 3 * NPIX2X + 3 * NPIX2Z + CONST_F4;
+    static constexpr int LDS_BYTES = LDS_F4 * 16;                          // 144,768
+    static_assert(6 * NPIX3X + 6 * NPIX3Z <= 2 * RING, "layer-3 maps must fit in the rings");
+    static_assert((2 * R2X) * (TX / 4) == 512 && (2 * R2Z) * (TZ / 4) == 512, "one pixel pair per thread of a group");
+};
+
+struct BandF {            // one band of one crop (all wave-uniform)
+    const float* in;      // this frame's crop (3, T, T)
+    int lgT, HALF, lgHALF, PITCH, npix1, p0, R2, lgW2, m2_off, pitch2, half2, npix2;
+    bool halo;            // top halo row comes from the other group's ring (else: image top, zeros)
+};
+
+__global__ __launch_bounds__(1024) void stem_fused_kernel(
+    const float* __restrict__ zin, const float* __restrict__ xin,                       // (B,3,64,64), (B,3,128,128)
+    const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
+    const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
+    const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip,
+    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    using G = FusedGeo;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    f4* const lds = reinterpret_cast<f4*>(lds_f);
+    f4* const ring0 = lds;                                   // group A's layer-1 ring
+    f4* const m2 = lds + 2 * G::RING;                        // layer-2 maps: x then z
+    constexpr int M2Z_OFF = 3 * G::NPIX2X;
+    f4* const m3x = lds;                                     // layer-3 maps reuse the rings (dead by then)
+    f4* const m3z = lds + 6 * G::NPIX3X;
+    f4* const cw2 = lds + 2 * G::RING + 3 * G::NPIX2X + 3 * G::NPIX2Z;   // [5][64] layer-2 weight images
+    const float* const cb2 = reinterpret_cast<const float*>(cw2 + 5 * 64);   // 16 floats
+    const float* const cb3 = cb2 + 16;                                       // 32
+    const float* const cb4 = cb3 + 32;                                       // 48
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 3, gw = wave & 7;
+    const int q = lane >> 4, px = lane & 15;
+    f4* const ring = ring0 + grp * G::RING;
+    const f4* const other_ring = ring0 + (1 - grp) * G::RING;
+
+    // band `s` of this wave's group: A = {z, x1, x3}, B = {x0, x2}
+    auto band = [&](int s) {
+        BandF J;
+        const bool is_z = grp == 0 && s == 0;
+        const int T = is_z ? G::TZ : G::TX;
+        const int xb = grp == 0 ? 2 * s - 1 : 2 * s;        // search band index (unused for z)
+        J.in = is_z ? zin + (size_t)b * 3 * G::TZ * G::TZ : xin + (size_t)b * 3 * G::TX * G::TX;
+        J.lgT = is_z ? 6 : 7; J.HALF = T >> 2; J.lgHALF = J.lgT - 2; J.PITCH = (T >> 1) + 1;
+        J.npix1 = is_z ? G::NPIX1Z : G::NPIX1X;
+        J.R2 = is_z ? G::R2Z : G::R2X; J.p0 = is_z ? 0 : xb * G::R2X; J.lgW2 = J.lgT - 2;
+        J.m2_off = is_z ? M2Z_OFF : 0; J.pitch2 = (T >> 2) + 1; J.half2 = T >> 3;
+        J.npix2 = is_z ? G::NPIX2Z : G::NPIX2X;
+        J.halo = !is_z && xb > 0;
+        return J;
+    };
+    const int nbands = grp == 0 ? 3 : 2;
+
+    // ---- layer 1 pieces ------------------------------------------------------------------------------
+    const int pair = gw * 64 + lane;                         // this thread's pixel pair of a band (0..511)
+    // Raw loads only: nothing here may depend on the loaded data, so the requests stay in flight across
+    // the layer-2 work and the barrier that follow (the top-of-image zeroing is applied in layer1).
+    auto fetch = [&](const BandF& J, f4 (&v)[3][3]) {
+        const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
+        const int p1 = 2 * J.p0 - 1 + lr;                    // layer-1 row (>= 0)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int iy = 2 * p1 + r - 1;                         // -1 only at the image top
+            iy = iy >= 0 ? iy : 0;
+            const unsigned off = ((unsigned)iy << J.lgT) + 4u * (unsigned)qp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off);
+        }
+    };
+    auto layer1 = [&](const BandF& J, const f4 (&v)[3][3]) {
+        // layer 1 is the long pole of an interval (VALU-bound); without this the issue arbiter favours the
+        // older group whatever it is doing, and the younger group's layer 1 takes three times as long
+        __builtin_amdgcn_s_setprio(3);
+        const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
+        const float keep0 = (2 * J.p0 - 1 + lr) > 0 ? 1.f : 0.f;   // kernel row 0 of layer-1 row 0 is the zero padding
+        // housekeeping by a few threads: column -1 of every ring row, and the halo row
+        const int nrow = 2 * J.R2 + 1;
+        if (pair < 2 * nrow) {
+            const int plane = pair >= nrow ? 1 : 0;
+            ring[plane * J.npix1 + (pair - plane * nrow) * J.PITCH + J.HALF] = splat4(0.f);
+        }
+        if (J.halo && pair >= 128 && pair < 128 + 2 * J.PITCH) {
+            const int e = pair - 128, plane = e >= J.PITCH ? 1 : 0, col = e - plane * J.PITCH;
+            ring[plane * J.npix1 + col] = other_ring[plane * J.npix1 + 2 * J.R2 * J.PITCH + col];
+        }
+        float a0[6], a1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+        float wa[18], wb[18];
+        load_section(wa, w1g, 0);
+#pragma unroll
+        for (int sec = 0; sec < 9; ++sec) {
+            float (&cur)[18] = (sec & 1) ? wb : wa;
+            float (&nxt)[18] = (sec & 1) ? wa : wb;
+            if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
+            const int r = sec / 3, c = sec % 3;
+            const f4 vv = r == 0 ? v[r][c] * splat4(keep0) : v[r][c];
+            const float left = lane_left(vv.w);               // a wave starts at a row start: lane 0 has qp = 0
+            const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
+                    a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]); a1[j] = hardswish(a1[j]); }
+        f4* dst = ring + lr * J.PITCH;
+        dst[qp] = f4{a0[0], a0[1], a0[2], a0[3]};                       // even column 2 qp, channels 0-3
+        dst[J.npix1 + qp] = f4{a0[4], a0[5], 0.f, 0.f};                 //                   channels 4-5 (+ padding)
+        dst[J.HALF + 1 + qp] = f4{a1[0], a1[1], a1[2], a1[3]};          // odd column 2 qp + 1
+        dst[J.npix1 + J.HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- layer 2: this group's ring -> the frame's layer-2 map ------------------------------------------
+    auto layer2 = [&](const BandF& J) {
+        f4 w2a[5][1];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w2a[c][0] = cw2[c * 64 + lane];
+        const f4 bv2 = ld4(cb2 + 4 * q);
+        int base[2], yy[2], xx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int op = 16 * (gw + 8 * i) + px;                       // 16 tiles per band: tiles gw and gw + 8
+            yy[i] = op >> J.lgW2; xx[i] = op & ((1 << J.lgW2) - 1);
+            base[i] = 2 * yy[i] * J.PITCH + xx[i];
+        }
+        f4 acc[2][1] = {{bv2}, {bv2}};
+        auto off2 = [&](int c) { return s2_chunk_off<2>(c, q, J.npix1, J.PITCH, J.HALF); };
+        vtc::mma_pass<1, 2, 5, 5, true>(ring, base, w2a, 0, off2, acc);
+        if (q < 3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f4 v = acc[i][0];
+                v.x = hardswish(v.x); v.y = hardswish(v.y); v.z = hardswish(v.z); v.w = hardswish(v.w);
+                const int x = xx[i];
+                m2[J.m2_off + q * J.npix2 + (J.p0 + yy[i] + 1) * J.pitch2 + ((x & 1) ? J.half2 + 1 + (x >> 1) : (x >> 1))] = v;
+            }
+        }
+    };
+
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (stamps != nullptr) {
+            unsigned long long tt;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+            if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
+            ++nstamp;
+        }
+    };
+    stamp();
+    // ---- start: the first bands' inputs are requested before the LDS is cleared ---------------------------
+    f4 v[3][3];
+    fetch(band(0), v);
+    {   // constants -> LDS; zero only what is read without ever being written: the top rows of the rings,
+        // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
+        const int t = threadIdx.x;
+        if (t < 5 * 64) cw2[t] = ld4(w2img + 4 * t);
+        else if (t < 5 * 64 + 4) cw2[t] = ld4(b2 + 4 * (t - 320));
+        else if (t < 5 * 64 + 12) cw2[t] = ld4(b3 + 4 * (t - 324));
+        else if (t < 5 * 64 + 24) cw2[t] = ld4(b4 + 4 * (t - 332));
+        else if (t >= 384 && t < 384 + 4 * 65) {                        // ring row 0: [2 rings][2 planes][65]
+            const int e = t - 384, rg = e / 130, pl = (e - rg * 130) / 65, col = e % 65;
+            ring0[rg * G::RING + pl * G::NPIX1X + col] = splat4(0.f);
+            if (rg == 0 && col < 33) ring0[pl * G::NPIX1Z + col] = splat4(0.f);   // ring A is first used with the z layout
+        } else if (t >= 704 && t < 704 + 3 * 66) {                      // search layer-2 map: row 0 and column -1
+            const int e = t - 704, pl = e / 66, k = e - pl * 66;
+            m2[pl * G::NPIX2X + (k < 33 ? k : (k - 33) * 33 + 16)] = splat4(0.f);
+        } else if (t >= 902 && t < 902 + 3 * 34) {                      // template layer-2 map
+            const int e = t - 902, pl = e / 34, k = e - pl * 34;
+            m2[M2Z_OFF + pl * G::NPIX2Z + (k < 17 ? k : (k - 17) * 17 + 8)] = splat4(0.f);
+        }
+    }
+    stamp();
+    __syncthreads();
+    stamp();
+
+    // ---- the staggered layer-1 / layer-2 pipeline --------------------------------------------------------
+    // Written out per group (no loop-carried registers: a prefetched band flows straight into its layer1).
+    // Both sequences execute the same six barriers.
+    // layer-3 / layer-4 weights of this wave are requested while the pipeline's last interval runs /
+    // while layer 3 runs, so their L2 round trips are not exposed
+    constexpr int NCH3 = 7, NCH4 = 14;
+    const int ot3 = wave & 1;
+    f4 w3a[NCH3][1];
+    auto load_w3 = [&]() { vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a); };
+    if (skip & 1) load_w3();
+    if (!(skip & 1)) {
+        const bool l2 = !(skip & 2);
+        if (grp == 0) {
+            layer1(band(0), v);                     stamp(); __syncthreads(); stamp();   // 0: L1(z)
+            fetch(band(1), v);
+            if (l2) layer2(band(0));                stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
+            layer1(band(1), v);                     stamp(); __syncthreads(); stamp();   // 2: L1(x1)
+            fetch(band(2), v);
+            if (l2) layer2(band(1));                stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
+            layer1(band(2), v);                     stamp(); __syncthreads(); stamp();   // 4: L1(x3)
+            load_w3();
+            if (l2) layer2(band(2));                stamp(); __syncthreads(); stamp();   // 5: L2(x3)
+        } else {
+            stamp(); __syncthreads(); stamp();   // 0: (x0 requested at kernel start)
+            layer1(band(0), v);                     stamp(); __syncthreads(); stamp();   // 1: L1(x0)
+            fetch(band(1), v);
+            if (l2) layer2(band(0));                stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
+            layer1(band(1), v);                     stamp(); __syncthreads(); stamp();   // 3: L1(x2)
+            if (l2) layer2(band(1));                stamp(); __syncthreads(); stamp();   // 4: L2(x2)
+            load_w3();                              __syncthreads();   // 5
+        }
+    }
+
+    // ---- layer 3 (12 -> 24, Hardswish) on the whole maps, all 16 waves -------------------------------------
+    // layer-4 work item of this wave: 15 (pixel tile, output tile) items, one per wave
+    const bool z4 = wave >= 12;
+    const int item4 = z4 ? wave - 12 : wave;
+    const int tile4 = z4 ? 0 : item4 / 3, ot4 = z4 ? item4 : item4 - 3 * tile4;
+    f4 w4a[NCH4][1];
+    if (wave < 15) vtc::load_weights<1, NCH4, NCH4>(w4img + (size_t)ot4 * NCH4 * 256, 0, NCH4, lane, w4a);
+    {
+        // pads of the layer-3 maps (they alias the rings, which hold layer-1 data): row 0 and column -1
+        for (int i = threadIdx.x; i < 6 * (2 * 17 + 2 * 9); i += 1024) {
+            const int plane = i / 52, e = i - plane * 52;
+            if (e < 17) m3x[plane * G::NPIX3X + e] = splat4(0.f);                               // row 0
+            else if (e < 34) m3x[plane * G::NPIX3X + (e - 17) * 17 + 8] = splat4(0.f);         // column -1
+            else if (e < 43) m3z[plane * G::NPIX3Z + (e - 34)] = splat4(0.f);
+            else m3z[plane * G::NPIX3Z + (e - 43) * 9 + 4] = splat4(0.f);
+        }
+        const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
+        if (!(skip & 4)) {
+            {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
+                constexpr int P2 = G::TX / 4 + 1, H2 = G::TX / 8, P3 = G::TX / 8 + 1, H3 = G::TX / 16;
+                int base[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) base[i] = 2 * ((wave >> 1) + 8 * i) * P2 + px;
+                f4 acc[2][1] = {{bv3}, {bv3}};
+                auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, G::NPIX2X, P2, H2); };
+                vtc::mma_pass<1, 2, NCH3, NCH3>(m2, base, w3a, 0, off3, acc);
+                if (16 * ot3 + 4 * q < 24) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        f4 r = acc[i][0];
+                        r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                        const int y = (wave >> 1) + 8 * i;
+                        // the store must wait until every wave has finished reading the rings?  No: layer 3 reads
+                        // only the layer-2 maps; the rings died at the pipeline's last barrier.
+                        m3x[(4 * ot3 + q) * G::NPIX3X + (y + 1) * P3 + ((px & 1) ? H3 + 1 + (px >> 1) : (px >> 1))] = r;
+                    }
+                }
+            }
+            if (wave < 8) {   // template: 4 pixel tiles of the 8 x 8 map
+                constexpr int P2 = G::TZ / 4 + 1, H2 = G::TZ / 8, P3 = G::TZ / 8 + 1, H3 = G::TZ / 16;
+                const int op = 16 * (wave >> 1) + px, y = op >> 3, x = op & 7;
+                int base[1] = {2 * y * P2 + x};
+                f4 acc[1][1] = {{bv3}};
+                auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, G::NPIX2Z, P2, H2); };
+                vtc::mma_pass<1, 1, NCH3, NCH3>(m2 + M2Z_OFF, base, w3a, 0, off3, acc);
+                if (16 * ot3 + 4 * q < 24) {
+                    f4 r = acc[0][0];
+                    r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                    m3z[(4 * ot3 + q) * G::NPIX3Z + (y + 1) * P3 + ((x & 1) ? H3 + 1 + (x >> 1) : (x >> 1))] = r;
+                }
+            }
+        }
+    }
+    stamp();
+    __syncthreads();
+    stamp();
+
+    // ---- layer 4 (24 -> 48) + pos-embed -> token rows: 15 (pixel tile, output tile) items, one per wave ------
+    if (wave < 15 && !(skip & 8)) {
+        const bool is_z = z4;
+        const int tile = tile4, ot = ot4;
+        const int lgS4 = is_z ? 2 : 3;
+        const int P3 = is_z ? G::TZ / 8 + 1 : G::TX / 8 + 1, H3 = is_z ? G::TZ / 16 : G::TX / 16;
+        const int npix3 = is_z ? G::NPIX3Z : G::NPIX3X;
+        const f4* map3 = is_z ? m3z : m3x;
+        const int op = 16 * tile + px, y = op >> lgS4, x = op & ((1 << lgS4) - 1);
+        int base[1] = {2 * y * P3 + x};
+        f4 acc[1][1] = {{ld4(cb4 + 16 * ot + 4 * q)}};
+        const f4 pe = ld4((is_z ? pos_z : pos_x) + (size_t)op * 48 + 16 * ot + 4 * q);   // requested before the MFMAs
+        auto off4 = [&](int c) { return s2_chunk_off<6>(c, q, npix3, P3, H3); };
+        vtc::mma_pass<1, 1, NCH4, NCH4>(map3, base, w4a, 0, off4, acc);
+        st4(tokens + ((size_t)b * L + (is_z ? 0 : len_z) + op) * 48 + 16 * ot + 4 * q, acc[0][0] + pe);
+    }
+    stamp();
+}
+
+}  // namespace vts
