@@ -76,6 +76,7 @@ struct vt_model {
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
     int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
+    int head_fused = 1;    // F = 8: head_fused_kernel (towers + decode in one workgroup per frame)
     int stem_fused = 1;    // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
@@ -282,7 +283,7 @@ template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
     const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
                        (size_t)vtb::small_floats(m->cfg.depth) * sizeof(float) +
-                       (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 16 : 0);
+                       (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 64 : 0);
     hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
                        resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps);
     HIP_TRY(hipGetLastError());
@@ -319,6 +320,13 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
     float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
+    if (m->F == 8 && m->head_fused) {
+        // towers + both decodes in one workgroup per frame
+        hipLaunchKernelGGL(vth::head_fused_kernel<8>, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p,
+                           m->window.p, score, size, offset, pred, hann, conf, m->skip_head);
+        HIP_TRY(hipGetLastError());
+        return VT_OK;
+    }
     if (m->F == 8) {
         hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
                            feat, m->head.p, score, size, offset, m->skip_head);
@@ -424,6 +432,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     m->stem_fused = env_int("VT_STEM_FUSED", 1);
+    m->head_fused = env_int("VT_HEAD_FUSED", 1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
@@ -456,6 +465,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16 + 49152);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vts::FusedGeo::LDS_BYTES);

@@ -225,4 +225,112 @@ __global__ __launch_bounds__(64) void decode_kernel(const float* __restrict__ sc
     }
 }
 
+// ---------------------------------------------------------------------------------------- fused head
+// All three towers of a frame in one workgroup of 12 waves (tower = wave / 4), then the two argmax
+// decodes from LDS: the token -> map staging is done once instead of three times, and the separate
+// decode launch (and its read-back of the maps) disappears.  LDS: one shared input map (12 quad
+// planes) + per tower 8 + 4 planes; fits for F = 8 (86 KB), not for F = 16.
+// The maps are still written to global memory (they are outputs of the boundary); any of
+// pred / hann / conf may be null, window may be null (then hann is skipped).
+template <int F>
+struct FusedHeadGeo {
+    using G = Geo<F>;
+    static constexpr int TOWER_F4 = (W1 / 4 + 4) * G::NPIX;                   // m1 (8 planes) + m2 (4 planes)
+    static constexpr int OUT_FLOATS = 5 * F * F;                               // score, size x2, offset x2
+    static constexpr int LDS_BYTES = ((C / 4) * G::NPIX + 3 * TOWER_F4) * 16 + OUT_FLOATS * 4;
+};
+
+template <int F>
+__global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                         const float* __restrict__ window, float* __restrict__ score,
+                                                         float* __restrict__ size, float* __restrict__ offset,
+                                                         float* __restrict__ pred, float* __restrict__ hann,
+                                                         float* __restrict__ conf, int skip) {   // skip: diagnostic
+    using G = Geo<F>;
+    using FG = FusedHeadGeo<F>;
+    static_assert(F * F == 64, "the in-kernel decode assumes one map pixel per lane of a wave");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    f4* in_map = reinterpret_cast<f4*>(sm);                                   // 12 quads, shared by the towers
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = wave >> 2, wv = wave & 3, tid = threadIdx.x - 256 * t;      // tower, wave / thread within the tower
+    f4* m1 = in_map + (C / 4) * G::NPIX + t * FG::TOWER_F4;                   // 8 quads
+    f4* m2 = m1 + (W1 / 4) * G::NPIX;                                         // 4 quads
+    float* outs = reinterpret_cast<float*>(in_map + (C / 4) * G::NPIX + 3 * FG::TOWER_F4);   // [5][F*F]
+    const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
+
+    HeadConv<C, W1, F> c1;
+    HeadConv<W1, 16, F> c2;
+    HeadConv<16, 8, F> c3;
+    HeadConv<8, 4, F> c4;
+    c1.prefetch(tw + O_W1, wv, lane);
+    if (!(skip & 1))
+        for (int i = threadIdx.x; i < (C / 4) * G::NPIX + 3 * FG::TOWER_F4; i += 768) in_map[i] = splat4(0.f);
+    __syncthreads();
+    // (B,HW,C) tokens -> quad planes, once for all towers   (vit_dist.py:126-129)
+    if (!(skip & 2))
+    for (int i = threadIdx.x; i < F * F * (C / 4); i += 768) {
+        const int icq = i / (F * F), pix = i % (F * F);
+        in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
+    }
+    __syncthreads();
+    c2.prefetch(tw + O_W2, wv, lane);
+    if (!(skip & 4)) c1.run(in_map, m1, tw + O_W1, tw + O_B1, wv, lane);
+    c3.prefetch(tw + O_W3, wv, lane);
+    __syncthreads();
+    if (!(skip & 8)) c2.run(m1, m2, tw + O_W2, tw + O_B2, wv, lane);
+    c4.prefetch(tw + O_W4, wv, lane);
+    __syncthreads();
+    if (!(skip & 16)) c3.run(m2, m1, tw + O_W3, tw + O_B3, wv, lane);
+    __syncthreads();
+    if (!(skip & 16)) c4.run(m1, m2, tw + O_W4, tw + O_B4, wv, lane);
+    __syncthreads();
+    // 1x1 conv + activation (head.py:187,194,200-201) -> global maps and the LDS copy for the decode
+    if (tid < F * F) {
+        const int pix = tid;
+        const f4 v = m2[(pix / F + 1) * G::P + (pix % F) + 1];
+        const int nout = (t == 0) ? 1 : 2;
+        for (int o = 0; o < nout; ++o) {
+            const f4 w5 = ld4(tw + O_W5 + 4 * o);
+            float y = tw[O_B5 + o];
+            y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
+            if (t == 0) { y = sigmoid_clamped(y); score[(size_t)b * F * F + pix] = y; outs[pix] = y; }
+            else if (t == 2) { y = sigmoid_clamped(y); size[((size_t)b * 2 + o) * F * F + pix] = y; outs[(1 + o) * F * F + pix] = y; }
+            else { offset[((size_t)b * 2 + o) * F * F + pix] = y; outs[(3 + o) * F * F + pix] = y; }
+        }
+    }
+    __syncthreads();
+    // cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105)
+    if (wave == 0) {
+        const float sc = outs[lane];
+        float v0 = sc, v1 = window != nullptr ? window[lane] * sc : -3.0e38f;
+        int i0 = lane, i1 = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
+            argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
+        }
+        if (lane == 0) {
+            constexpr int n = F * F;
+            const float fF = (float)F;
+            const float* sz = outs + n;
+            const float* of = outs + 3 * n;
+            if (pred != nullptr) {
+                pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
+                pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
+                pred[b * 4 + 2] = sz[i0];
+                pred[b * 4 + 3] = sz[n + i0];
+            }
+            if (hann != nullptr && window != nullptr) {
+                hann[b * 4 + 0] = ((float)(i1 % F) + of[i1]) / fF;
+                hann[b * 4 + 1] = ((float)(i1 / F) + of[n + i1]) / fF;
+                hann[b * 4 + 2] = sz[i1];
+                hann[b * 4 + 3] = sz[n + i1];
+            }
+            if (conf != nullptr) conf[b] = v0;
+        }
+    }
+}
+
 }  // namespace vth

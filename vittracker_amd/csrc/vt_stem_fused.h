@@ -214,10 +214,12 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         else if (t < 5 * 64 + 4) cw2[t] = ld4(b2 + 4 * (t - 320));
         else if (t < 5 * 64 + 12) cw2[t] = ld4(b3 + 4 * (t - 324));
         else if (t < 5 * 64 + 24) cw2[t] = ld4(b4 + 4 * (t - 332));
-        else if (t >= 384 && t < 384 + 4 * 65) {                        // ring row 0: [2 rings][2 planes][65]
-            const int e = t - 384, rg = e / 130, pl = (e - rg * 130) / 65, col = e % 65;
-            ring0[rg * G::RING + pl * G::NPIX1X + col] = splat4(0.f);
-            if (rg == 0 && col < 33) ring0[pl * G::NPIX1Z + col] = splat4(0.f);   // ring A is first used with the z layout
+        else if (t >= 384 && t < 384 + 2 * 65) {                        // ring B, row 0 (first used by x0: image top)
+            const int e = t - 384, pl = e / 65, col = e - pl * 65;
+            ring0[G::RING + pl * G::NPIX1X + col] = splat4(0.f);
+        } else if (t >= 520 && t < 520 + 2 * 33) {                      // ring A, row 0 in the z layout (its x bands copy a halo)
+            const int e = t - 520, pl = e / 33, col = e - pl * 33;
+            ring0[pl * G::NPIX1Z + col] = splat4(0.f);
         } else if (t >= 704 && t < 704 + 3 * 66) {                      // search layer-2 map: row 0 and column -1
             const int e = t - 704, pl = e / 66, k = e - pl * 66;
             m2[pl * G::NPIX2X + (k < 33 ? k : (k - 33) * 33 + 16)] = splat4(0.f);
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         }
     }
     stamp();
-    __syncthreads();
+    // No barrier here: nothing written above is read before the first interval's barrier (layer 1 reads no LDS,
+    // and its ring writes do not overlap the entries cleared above).
     stamp();
 
     // ---- the staggered layer-1 / layer-2 pipeline --------------------------------------------------------
