@@ -331,7 +331,8 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
                            feat, m->head.p, score, size, offset, m->skip_head);
     } else if (m->F == 16) {
-        hipLaunchKernelGGL(vth::head_towers_kernel<16>, dim3(B, 3), dim3(256), vth::Geo<16>::LDS_BYTES,
+        // 129 KB of LDS per tower = one workgroup per CU: 8 waves give every SIMD two instruction streams
+        hipLaunchKernelGGL((vth::head_towers_kernel<16, 8>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES,
                            st, feat, m->head.p, score, size, offset, m->skip_head);
     } else {
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
@@ -472,7 +473,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vts::FusedGeo::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(vth::Geo<16>::LDS_BYTES));
         if (e != hipSuccess) rc = fail(VT_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));

@@ -65,13 +65,15 @@ struct Geo {
 // pixel tiles four ways.  Weights move in passes of <= 9 chunks, double-buffered: prefetch() issues
 // pass 0 (callable a whole layer early -- weights do not depend on activations) and run() requests
 // pass p+1 before the MFMAs of pass p.
-template <int CIN, int COUT, int F>
+// NW = waves working on one tower (4, or 8 where LDS allows only one workgroup per CU: two waves per SIMD).
+template <int CIN, int COUT, int F, int NW = 4>
 struct HeadConv {
     using G = Geo<F>;
     static constexpr int NQ = CIN / 4, NCH = nchunks(CIN), NOT = ntiles(COUT);
     static constexpr bool SPLIT_OT = NOT == 2;
-    static constexpr int NPT = SPLIT_OT ? G::NT / 2 : G::NT / 4;
-    static constexpr int TSTEP = SPLIT_OT ? 2 : 4;
+    static constexpr int TSTEP = SPLIT_OT ? NW / 2 : NW;
+    static constexpr int NPT = G::NT / TSTEP;
+    static_assert(G::NT % TSTEP == 0 && NPT >= 1, "pixel tiles must divide over the waves");
     static constexpr int MAXC = NCH < 9 ? NCH : 9;
     static constexpr int NPASS = (NCH + MAXC - 1) / MAXC;
     static_assert(NOT <= 2, "layers here have at most 2 output tiles");
@@ -121,8 +123,8 @@ struct HeadConv {
 };
 
 // grid (B, 3): tower 0 = ctr, 1 = offset, 2 = size.   feat: (B, F*F, 48) normalised search tokens.
-template <int F>
-__global__ __launch_bounds__(256) void head_towers_kernel(const float* __restrict__ feat,
+template <int F, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ hw,
                                                           float* __restrict__ score, float* __restrict__ size,
                                                           float* __restrict__ offset, int skip) {   // skip: diagnostic
@@ -136,17 +138,17 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
 
-    HeadConv<C, W1, F> c1;
-    HeadConv<W1, 16, F> c2;
-    HeadConv<16, 8, F> c3;
-    HeadConv<8, 4, F> c4;
+    HeadConv<C, W1, F, NW> c1;
+    HeadConv<W1, 16, F, NW> c2;
+    HeadConv<16, 8, F, NW> c3;
+    HeadConv<8, 4, F, NW> c4;
     c1.prefetch(tw + O_W1, wave, lane);        // first weight burst flies during the map set-up
     if (!(skip & 1))
-        for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += 256) in_map[i] = splat4(0.f);
+        for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += NW * 64) in_map[i] = splat4(0.f);
     __syncthreads();
     // (B,HW,C) tokens -> quad planes: map[c/4][p][q] = feat[b][p*F+q][c..c+3]   (vit_dist.py:126-129)
     if (!(skip & 2))
-    for (int i = threadIdx.x; i < F * F * (C / 4); i += 256) {
+    for (int i = threadIdx.x; i < F * F * (C / 4); i += NW * 64) {
         const int icq = i / (F * F), pix = i % (F * F);
         in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] =
             ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void head_towers_kernel(const float* __restric
     if (!(skip & 16)) c4.run(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
     __syncthreads();
     // 1x1 conv + activation (head.py:187,194,200-201)
-    for (int pix = threadIdx.x; pix < F * F; pix += 256) {
+    for (int pix = threadIdx.x; pix < F * F; pix += NW * 64) {
         const f4 v = m2[(pix / F + 1) * G::P + (pix % F) + 1];
         const int nout = (t == 0) ? 1 : 2;
         for (int o = 0; o < nout; ++o) {
