@@ -77,6 +77,7 @@ struct vt_model {
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
     int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
     int head_fused = 1;    // F = 8: head_fused_kernel (towers + decode in one workgroup per frame)
+    int stem_pipe = 1;     // G256: stem_pipe_kernel (layers 1 + 2 per frame) instead of stem_a
     int stem_fused = 1;    // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
@@ -254,12 +255,20 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         HIP_TRY(hipGetLastError());
         return VT_OK;
     }
+    const bool pipe = m->stem_pipe && Tx == 256 && Tz == 128;
+    if (pipe) {   // layers 1 + 2 of a frame in one workgroup (two wave groups half a period apart); stem_b follows
+        constexpr size_t lds_p = vts::PipeGeo<256, 128>::LDS_BYTES;
+        hipLaunchKernelGGL((vts::stem_pipe_kernel<256, 128>), dim3(B), dim3(1024), lds_p, st, z, x,
+                           m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps);
+        HIP_TRY(hipGetLastError());
+    }
     vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
     // fused form: band k of both crops in one workgroup, when the template band then has exactly one
     // layer-2 tile per wave and the workgroup count fills whole rounds of 4 per CU better than the split form
     const int r2z_f = (Tz / 4) / ax.bands;
     const bool fuse = m->stem_fuse && r2z_f >= 1 && r2z_f * ax.bands == Tz / 4 && r2z_f * (Tz / 4) == 64;
-    if (fuse) {
+    if (pipe) {
+    } else if (fuse) {
         az.r2 = r2z_f; az.bands = ax.bands;
         const size_t lds_a = sizeof(float) * (vts::stem_a_lds_floats(Tx, ax.r2) + vts::stem_a_lds_floats(Tz, az.r2));
         hipLaunchKernelGGL(vts::stem_a2_kernel, dim3(B * ax.bands), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
@@ -433,6 +442,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     m->stem_fused = env_int("VT_STEM_FUSED", 1);
+    m->stem_pipe = env_int("VT_STEM_PIPE", 1);
     m->head_fused = env_int("VT_HEAD_FUSED", 1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
@@ -469,6 +479,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_pipe_kernel<256, 128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)vts::PipeGeo<256, 128>::LDS_BYTES);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_fused_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vts::FusedGeo::LDS_BYTES);

@@ -342,4 +342,173 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     stamp();
 }
 
+// ------------------------------------------------------------------------------------------ stem_pipe
+// Layers 1 + 2 of both crops of one frame in one workgroup, for geometries whose layer-2 maps do not fit
+// in LDS (G256): the layer-1 / layer-2 half of stem_fused_kernel -- two 8-wave groups half a period apart,
+// one on the VALU layer, the other on the MFMA layer of the previous band -- as a loop over the frame's
+// bands (template crop first), with layer 2 writing the channel-quad planes that stem_b reads.
+// Replaces stem_a, whose four workgroups per CU run the two layers in lock step (their times add up).
+template <int TX, int TZ>
+struct PipeGeo {
+    static constexpr int R2X = 1024 / TX, R2Z = 1024 / TZ;       // 512 pixel pairs per band = one per thread of a group
+    static constexpr int NBX = (TX / 4) / R2X, NBZ = (TZ / 4) / R2Z, NB = NBX + NBZ;
+    static constexpr int NPIX1X = round16((2 * R2X + 1) * (TX / 2 + 1));
+    static constexpr int NPIX1Z = round16((2 * R2Z + 1) * (TZ / 2 + 1));
+    static constexpr int RING = 2 * (NPIX1X > NPIX1Z ? NPIX1X : NPIX1Z);
+    static constexpr int CONST_F4 = 5 * 64 + 4;                  // layer-2 weight images, b2
+    static constexpr int LDS_BYTES = (2 * RING + CONST_F4) * 16;
+    static_assert(NB % 2 == 0 && NBZ % 2 == 0, "bands alternate between the two groups, crop by crop");
+    static_assert((R2X * (TX / 4)) == 256 && (R2Z * (TZ / 4)) == 256, "16 layer-2 tiles per band");
+};
+
+template <int TX, int TZ>
+__global__ __launch_bounds__(1024) void stem_pipe_kernel(
+    const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
+    const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip,
+    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    using G = PipeGeo<TX, TZ>;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    f4* const ring0 = reinterpret_cast<f4*>(lds_f);
+    f4* const cw2 = ring0 + 2 * G::RING;
+    const float* const cb2 = reinterpret_cast<const float*>(cw2 + 5 * 64);
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 3, gw = wave & 7;
+    const int q = lane >> 4, px = lane & 15;
+    f4* const ring = ring0 + grp * G::RING;
+    const f4* const other_ring = ring0 + (1 - grp) * G::RING;
+    const int pair = gw * 64 + lane;
+
+    struct Band {
+        const float* in; float* out;
+        int lgT, HALF, lgHALF, PITCH, npix1, p0, R2, lgW2;
+        bool halo;
+    };
+    auto band = [&](int j) {       // j-th band of the frame: template bands first
+        Band J;
+        const bool is_z = j < G::NBZ;
+        const int kb = is_z ? j : j - G::NBZ;
+        constexpr int lgTX = TX == 256 ? 8 : 7, lgTZ = TZ == 128 ? 7 : 6;
+        static_assert((1 << lgTX) == TX && (1 << lgTZ) == TZ, "crop sides");
+        J.in = is_z ? zin + (size_t)b * 3 * TZ * TZ : xin + (size_t)b * 3 * TX * TX;
+        J.out = is_z ? act_z + (size_t)b * 3 * (TZ / 4) * (TZ / 4) * 4 : act_x + (size_t)b * 3 * (TX / 4) * (TX / 4) * 4;
+        J.lgT = is_z ? lgTZ : lgTX; J.HALF = (is_z ? TZ : TX) >> 2; J.lgHALF = J.lgT - 2; J.PITCH = ((is_z ? TZ : TX) >> 1) + 1;
+        J.npix1 = is_z ? G::NPIX1Z : G::NPIX1X; J.R2 = is_z ? G::R2Z : G::R2X; J.p0 = kb * J.R2; J.lgW2 = J.lgT - 2;
+        J.halo = kb > 0;
+        return J;
+    };
+    auto fetch = [&](const Band& J, f4 (&v)[3][3]) {           // raw loads only (see stem_fused_kernel)
+        const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
+        const int p1 = 2 * J.p0 - 1 + lr;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int iy = 2 * p1 + r - 1;
+            iy = iy >= 0 ? iy : 0;
+            const unsigned off = ((unsigned)iy << J.lgT) + 4u * (unsigned)qp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off);
+        }
+    };
+    auto layer1 = [&](const Band& J, const f4 (&v)[3][3]) {
+        __builtin_amdgcn_s_setprio(3);
+        const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
+        const float keep0 = (2 * J.p0 - 1 + lr) > 0 ? 1.f : 0.f;
+        const int nrow = 2 * J.R2 + 1;
+        if (pair < 2 * nrow) {                                  // column -1 of every ring row
+            const int plane = pair >= nrow ? 1 : 0;
+            ring[plane * J.npix1 + (pair - plane * nrow) * J.PITCH + J.HALF] = splat4(0.f);
+        }
+        if (pair >= 128 && pair < 128 + 2 * J.PITCH) {          // row 0: the previous band's last row, or the image top
+            const int e = pair - 128, plane = e >= J.PITCH ? 1 : 0, col = e - plane * J.PITCH;
+            ring[plane * J.npix1 + col] = J.halo ? other_ring[plane * J.npix1 + 2 * J.R2 * J.PITCH + col] : splat4(0.f);
+        }
+        float a0[6], a1[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) a0[j] = a1[j] = b1[j];
+        float wa[18], wb[18];
+        load_section(wa, w1g, 0);
+#pragma unroll
+        for (int sec = 0; sec < 9; ++sec) {
+            float (&cur)[18] = (sec & 1) ? wb : wa;
+            float (&nxt)[18] = (sec & 1) ? wa : wb;
+            if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
+            const int r = sec / 3, c = sec % 3;
+            const f4 vv = r == 0 ? v[r][c] * splat4(keep0) : v[r][c];
+            const float left = lane_left(vv.w);
+            const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    a0[j] = fmaf(t0[s], cur[s * 6 + j], a0[j]);
+                    a1[j] = fmaf(t1[s], cur[s * 6 + j], a1[j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a0[j] = hardswish(a0[j]); a1[j] = hardswish(a1[j]); }
+        f4* dst = ring + lr * J.PITCH;
+        dst[qp] = f4{a0[0], a0[1], a0[2], a0[3]};
+        dst[J.npix1 + qp] = f4{a0[4], a0[5], 0.f, 0.f};
+        dst[J.HALF + 1 + qp] = f4{a1[0], a1[1], a1[2], a1[3]};
+        dst[J.npix1 + J.HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto layer2 = [&](const Band& J) {
+        f4 w2a[5][1];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) w2a[c][0] = cw2[c * 64 + lane];
+        const f4 bv2 = ld4(cb2 + 4 * q);
+        int base[2], yy[2], xx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int op = 16 * (gw + 8 * i) + px;
+            yy[i] = op >> J.lgW2; xx[i] = op & ((1 << J.lgW2) - 1);
+            base[i] = 2 * yy[i] * J.PITCH + xx[i];
+        }
+        f4 acc[2][1] = {{bv2}, {bv2}};
+        auto off2 = [&](int c) { return s2_chunk_off<2>(c, q, J.npix1, J.PITCH, J.HALF); };
+        vtc::mma_pass<1, 2, 5, 5, true>(ring, base, w2a, 0, off2, acc);
+        if (q < 3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f4 r = acc[i][0];
+                r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                st4(J.out + ((((size_t)q << (2 * J.lgW2)) + (((size_t)J.p0 + yy[i]) << J.lgW2) + xx[i]) << 2), r);   // quad plane q
+            }
+        }
+    };
+
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (stamps != nullptr && nstamp < 32) {
+            unsigned long long tt;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+            if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
+            ++nstamp;
+        }
+    };
+    stamp();
+    f4 v[3][3];
+    fetch(band(grp), v);
+    if (threadIdx.x < 5 * 64) cw2[threadIdx.x] = ld4(w2img + 4 * threadIdx.x);
+    else if (threadIdx.x < 5 * 64 + 4) cw2[threadIdx.x] = ld4(b2 + 4 * (threadIdx.x - 320));
+    // group B works one interval behind group A; both execute NB + 1 barriers
+    if (grp == 1) __syncthreads();
+    for (int s = 0; s < G::NB / 2; ++s) {
+        const int j = 2 * s + grp;
+        if (!(skip & 1)) layer1(band(j), v);
+        stamp();
+        __syncthreads();
+        stamp();
+        fetch(band(j + 2 < G::NB ? j + 2 : j), v);              // the next band of this group, a whole interval ahead
+        if (!(skip & 2)) layer2(band(j));
+        stamp();
+        __syncthreads();
+        stamp();
+    }
+    if (grp == 0) __syncthreads();
+}
+
 }  // namespace vts
