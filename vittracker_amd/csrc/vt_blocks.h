@@ -181,8 +181,8 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
 //     proj        guest g < 3: output tile g -> Dg (LDS); every guest adds all three        (12)
 //     LN2 + fc1   guest g: hidden tiles 3g..3g+2, GELU                                      (36)
 //     fc2         K-split: guest g contracts its own hidden tiles -> partial in LDS; summed (36)
-// Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream
-// whose MFMAs fill the owner's LayerNorm / softmax / GELU sections.
+// Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream that
+// fills the owner's waits (f32 MFMA and VALU issue add up even across waves: tools/src/probe_overlap.hip).
 template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
 __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*

@@ -17,8 +17,9 @@
 //
 // L1 = layer 1 (3 -> 6, VALU, reads the crop from HBM; 512 pixel pairs = one per thread) into the
 // group's own LDS ring; L2 = layer 2 (6 -> 12, MFMA) from that ring into the frame's layer-2 map.
-// While one group's VALU pipe work runs, the other group's MFMAs use the matrix pipe of the same
-// SIMDs.  A band's input is fetched one interval ahead (during the group's L2), so HBM latency is
+// The two groups do not co-issue (f32 MFMA and VALU share the SIMD's issue, tools/src/probe_overlap.hip); what the
+// stagger buys is that one group's waits -- HBM latency, scalar weight loads, LDS round trips -- are filled by the
+// other group's work, and that only token rows ever leave the CU.  A band's input is fetched one interval ahead (during the group's L2), so HBM latency is
 // exposed once per frame.  A band's top halo row is the previous band's last row, copied from the
 // other group's ring (stable while that group is in its L2 interval).  Then all 16 waves run layer 3
 // (12 -> 24) and layer 4 (24 -> 48) + pos-embed as in stem_b, on whole maps.
