@@ -17,7 +17,7 @@ Extra objects in that line:
                 fp32 MFMA/VALU peak of MI355X_MICROARCH.md.
   cpu_baseline  the torch fp32 restatement of the reference module graph (oracle/, kind "port")
                 timed on this box's host cores on a bounded sample.
-  stages_us, also   per-stage durations and the G256 (shipped-YAML geometry) throughput.
+  stages_us, also   per-stage durations, the G256 (shipped-YAML geometry) throughput and a G128 batch sweep (1/16/64).
 """
 from __future__ import annotations
 
@@ -240,6 +240,14 @@ def main():
                 line["also"] = {"G256_frames_per_s": round(B / t256 * 1e6, 1),
                                 "G256_frac_fp32_peak": round(B / t256 * 1e6 * 2 * sum(m256.values()) / 1e12 / PEAK_FP32_TFLOPS, 4),
                                 "G256_note": "shipped YAML geometry 256/128, 320 tokens, batch %d" % B}
+                del r2
+                sweep = {}     # smaller batches (one workgroup per frame: latency-bound below 256 frames)
+                for bs in (1, 16, 64):
+                    rb = Runner(a.geom, bs)
+                    t = rb.time_us(lambda: rb.graph.launch(rb.stream), max(50, a.steps // 2))
+                    sweep[str(bs)] = {"us_per_step": round(t, 2), "frames_per_s": round(bs / t * 1e6, 1)}
+                    del rb
+                line["also"]["G128_batch_sweep"] = sweep
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
