@@ -4,15 +4,17 @@
 // Replaces Conv2d_BN / b16 / LevitPatchEmbedding.forward and the pos-embed add + cat of
 // OstrackDist.forward (lib/models/vit_dist/vit_dist.py:10-54,78-84).
 //
-// Two kernels, both crops (z and x) in the same launch:
+// The two-kernel form (both crops in each launch).  The default paths are stem_fused_kernel (G128: all four
+// layers of a frame in one workgroup) and stem_pipe_kernel + stem_b (G256), both in vt_stem_fused.h; stem_a /
+// stem_a2 stay selectable (VT_STEM_FUSED / VT_STEM_PIPE = 0) and parity-tested.
 //
 //  stem_a  layers 1+2, the HBM-streaming half.  One workgroup per (frame, crop, band of R2 layer-2
-//          rows).  Layer 1 (3 -> 6) reads the NCHW crop straight from HBM -- each wave-instruction
-//          covers whole 512/1024-byte image rows with float4 loads, two output pixels per thread --
-//          and leaves its 2*R2+1 output rows in LDS (never in HBM).  Layer 2 (6 -> 12) reads them
-//          back with unit-stride ds_read_b32 thanks to a column-parity split (even | odd halves per
-//          row) and writes NHWC(12).  Both layers run on the VALU with their folded weights as
-//          wave-uniform SGPR operands: at 6 / 12 output channels an MFMA tile would be 37-75 % padding.
+//          rows).  Layer 1 (3 -> 6, VALU: an MFMA tile would be 64 % padding) reads the NCHW crop straight
+//          from HBM -- each wave-instruction covers whole 512/1024-byte image rows with float4 loads, two
+//          output pixels per thread, folded weights as wave-uniform SGPR operands -- and leaves its 2*R2+1
+//          output rows in LDS as a column-parity-split quad-planar map.  Layer 2 (6 -> 12, channels padded
+//          to 8) is an implicit GEMM on MFMA over that map and writes the result as three channel-quad
+//          planes (B, 3, S2, S2, 4).  stem_a2: the same with band k of both crops in one workgroup.
 //
 //  stem_b  layers 3+4 on v_mfma_f32_16x16x4_f32 as implicit GEMMs (weights = A operand, 16 output
 //          pixels = B operand columns), one workgroup per (frame, crop, band of R4 token rows).
