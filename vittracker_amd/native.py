@@ -50,6 +50,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise VtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"or `make -C vittracker_amd/csrc` (there is no CPU fallback)")
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  It has to be loaded before this library pulls in the
+    # system libamdhip64: in the opposite order torch.cuda.is_available() turns False for the rest of the process
+    # (seen when a process created a Model before it had ever imported torch).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32 = C.c_void_p, C.c_int32
     L.vt_last_error.restype = C.c_char_p
