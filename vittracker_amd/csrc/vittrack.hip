@@ -698,9 +698,9 @@ int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_
     if (rc) return rc;
     if (!g) return fail(VT_ERR_ARG, "null graph out");
     // The batch is captured as NCH independent chains over frame slices (fork / join with events):
-    // the five kernels of one slice then overlap the kernels of the others instead of running
-    // strictly one after another with a fixed start-up cost and a tail each.
-    int nch = m->graph_chains;   // measured: 2 chains cost +12 % at G128/B=256, -3 % at G256; default 1
+    // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
+    // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
+    int nch = m->graph_chains;   // default 1
     nch = std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
@@ -744,7 +744,8 @@ void vt_graph_destroy(vt_graph* g) {
 }
 
 int vt_debug_stamps(vt_model* m, int32_t B, unsigned long long* host_out) {
-    // Development aid: copies the block kernel's phase stamps ([B][5 waves][32]) of the last launch.
+    // Development aid: copies the in-kernel s_memtime stamps of the last launch (block kernel: [B][waves][64];
+    // stem_fused / stem_pipe: [B][16][32]); the buffer holds B * 8 * 64 values.
     if (!m || !m->dbg_stamps || !host_out) return fail(VT_ERR_STATE, "stamps are off (set VT_DBG_STAMPS=1 before vt_create)");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(host_out, m->dbg_stamps, (size_t)B * 8 * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
