@@ -187,3 +187,26 @@ def test_result_gather_two_ranks_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+# ---------------------------------------------------------------- bench.py launcher (no GPU: gloo, compute skipped)
+def test_bench_self_launches_two_ranks_plumbing_only():
+    """`python bench.py --gpus 2` with no torch.distributed.run wrapper: the parent spawns the ranks as a
+    child, relays ONE JSON line and exits with the child's code (here on gloo with compute skipped)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "3",
+                        "--warmup", "1", "--batch", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and len(j["per_rank_frames_per_s"]) == 2
+    assert "gather_exposed_us_per_step" in j and j["scaling"] == "weak"
+
+
+def test_bench_refuses_diagnostic_switches():
+    env = dict(os.environ, VT_SKIP_HEAD="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--plumbing-only", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refuses to run" in (r.stdout + r.stderr)

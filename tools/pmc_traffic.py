@@ -17,6 +17,12 @@ for k, c in acc.items():
     out[k] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import subprocess
+from bench import kernel_source_hash
+out["_kernel_source_hash"] = kernel_source_hash()   # bench.py quotes the figure only for these exact sources
+out["_commit"] = (sys.argv[3] if len(sys.argv) > 3 else
+                  subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown")
 allj[key] = out
 json.dump(allj, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))

@@ -18,6 +18,17 @@ import numpy as np
 from .config import geometry
 from .host_ops import hann2d
 from .model import build_ostrack_dist
+from .native import VtError
+
+
+def check_params_geometry(params, nat):
+    """The tracker crops at params.{template,search}_size (TEST.*_SIZE) while the model is built from
+    DATA.*.SIZE: a YAML that sets only one of them raises a shape error at the pos-embed add in the
+    reference (lib/models/vit_dist/vit_dist.py:81-82); here the mismatch is refused up front."""
+    if (params.template_size, params.search_size) != (nat.template_size, nat.search_size):
+        raise VtError(f"tracker crop sizes (TEST.TEMPLATE_SIZE={params.template_size}, TEST.SEARCH_SIZE="
+                      f"{params.search_size}) differ from the model geometry (DATA.TEMPLATE.SIZE={nat.template_size}, "
+                      f"DATA.SEARCH.SIZE={nat.search_size})")
 
 
 class BatchedVitTracker:
@@ -36,6 +47,7 @@ class BatchedVitTracker:
             raise FileNotFoundError(f"checkpoint {ckpt!r} not found")
         self.net.cuda().eval()
         self.nat = self.net._native()
+        check_params_geometry(params, self.nat)
         F = params.search_size // self.cfg.MODEL.BACKBONE.STRIDE
         self.nat.set_window(hann2d(torch.tensor([F, F]).long()).numpy())
         self.mean, self.std = list(self.cfg.DATA.MEAN), list(self.cfg.DATA.STD)
@@ -46,23 +58,43 @@ class BatchedVitTracker:
         self.rf = torch.zeros(batch, dtype=torch.float64, device=dev)
         self.graph, self.out = self.nat.capture(self.z, self.x)
         self.frames = None
+        self._pinned = None
+        self._h2d_done = None
+        self._slot = 0
         self.hw = None
         self.frame_id = 0
 
     def _upload(self, frames):
+        """Host frames go through two pinned staging buffers, each guarded by an event recorded after
+        its H2D copy: with track(sync=False) the host may run ahead of the device, and a staging
+        buffer is only rewritten once the copy that last read it has finished.  The device-side frame
+        buffer is also double-buffered: the crop kernel of step f may still be reading it when the
+        copy of step f+1 is queued on the same stream -- stream order covers that, the two slots
+        simply keep a host thread that uploads from a side stream safe too."""
         import torch
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
             t = frames
+            if t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3 or t.shape[0] != self.B or not t.is_contiguous():
+                raise ValueError(f"frames must be a contiguous (B={self.B}, H, W, 3) uint8 tensor")
         else:
             a = np.ascontiguousarray(np.stack(frames) if not isinstance(frames, np.ndarray) else frames)
             if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3 or a.shape[0] != self.B:
                 raise ValueError(f"frames must be (B={self.B}, H, W, 3) uint8")
-            if self.frames is None or tuple(self.frames.shape) != a.shape:
-                self.frames = torch.empty(a.shape, dtype=torch.uint8, device="cuda")
-                self._pinned = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
-            self._pinned.copy_(torch.from_numpy(a))
-            self.frames.copy_(self._pinned, non_blocking=True)
-            t = self.frames
+            if self.frames is None or tuple(self.frames[0].shape) != a.shape:
+                torch.cuda.current_stream().synchronize()      # nothing may still read the old buffers
+                self.frames = [torch.empty(a.shape, dtype=torch.uint8, device="cuda") for _ in range(2)]
+                self._pinned = [torch.empty(a.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+                self._h2d_done = [None, None]
+            k = self._slot
+            self._slot ^= 1
+            if self._h2d_done[k] is not None:
+                self._h2d_done[k].synchronize()                # the copy that last read this staging buffer
+            self._pinned[k].copy_(torch.from_numpy(a))
+            self.frames[k].copy_(self._pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._h2d_done[k] = ev
+            t = self.frames[k]
         self.hw = (int(t.shape[1]), int(t.shape[2]))
         return t
 

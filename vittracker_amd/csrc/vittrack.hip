@@ -288,11 +288,18 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     return VT_OK;
 }
 
+// dynamic LDS of blocks_kernel<NT, ., ., WLDS, BAL> at a given depth: K/V images, weight staging buffers,
+// the small parameters (LayerNorm vectors + biases of every block) and the guests' exchange area
+size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth) {
+    return ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
+           (size_t)vtb::small_floats(depth) * sizeof(float) +
+           (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 64 : 0);
+}
+constexpr size_t LDS_PER_CU = 160 * 1024;
+
 template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
-    const size_t lds = ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
-                       (size_t)vtb::small_floats(m->cfg.depth) * sizeof(float) +
-                       (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 64 : 0);
+    const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth);
     hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
                        resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps);
     HIP_TRY(hipGetLastError());
@@ -413,6 +420,12 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         return fail(VT_ERR_ARG, "unsupported geometry (template,search)=(" + std::to_string(cfg->template_size) + "," +
                                     std::to_string(cfg->search_size) + "); supported: (64,128), (128,256)");
     if (cfg->depth < 1 || cfg->depth > 12 || cfg->max_batch < 1) return fail(VT_ERR_ARG, "bad depth / max_batch");
+    {   // the block kernel keeps every block's LayerNorm vectors and biases in LDS next to the K/V images
+        const size_t need = g128 ? blocks_lds_bytes(5, true, true, cfg->depth) : blocks_lds_bytes(20, false, false, cfg->depth);
+        if (need > LDS_PER_CU)
+            return fail(VT_ERR_ARG, "depth " + std::to_string(cfg->depth) + " needs " + std::to_string(need) +
+                                        " B of LDS per workgroup at this geometry (limit " + std::to_string(LDS_PER_CU) + ")");
+    }
 
     vt_model* m = new vt_model();
     m->cfg = *cfg;
@@ -462,20 +475,23 @@ int vt_create(const vt_config* cfg, vt_model** out) {
             rc = fail(VT_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     if (!rc && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) rc = fail(VT_ERR_HIP, "hipEventCreate failed");
     if (!rc) {
-        // > 64 KiB of dynamic LDS needs an explicit opt-in
+        // > 64 KiB of dynamic LDS needs an explicit opt-in; the limits are the exact sizes launch_blocks computes
+        const int small_bytes = vtb::small_floats(cfg->depth) * (int)sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 4, 5, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16 + 16384);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 5, 1, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16 + 16384);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, false, cfg->depth));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 5, 1, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, false, false, cfg->depth));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 20 * vtb::NC * 64 * 16 + 16384);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (2 * 5 * vtb::NC + 2 * vtb::WBUF_TILES) * 64 * 16 + 49152);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth));
+        (void)small_bytes;
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);

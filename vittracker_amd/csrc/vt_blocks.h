@@ -130,6 +130,14 @@ __device__ __forceinline__ void layer_norm_img(const f4 (&x)[NC], f4 (&h)[NC], c
 // A buffer is refilled only after the barrier that ends its last reader; __syncthreads() waits
 // for the DMA (vmcnt) before it releases the readers.
 constexpr int WBUF_TILES = NH * NC;   // 36: fc1 / fc2
+// A barrier that publishes LDS-DMA staged weights to the other waves.  global_load_lds is tracked by vmcnt,
+// while at workgroup scope the memory model only promises lgkmcnt(0) in front of a barrier: hipcc (ROCm 7.2)
+// happens to emit vmcnt(0) there as well, but that is compiler behaviour, so the wait is written out.
+template <bool STAGED>
+__device__ __forceinline__ void barrier_publish() {
+    if constexpr (STAGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 __device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ src, int ntiles, int w, int nw, int lane) {
     for (int t = w; t < ntiles; t += nw)
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         // barriers), but the issue arbiter favours the older owner waves: raise the guests' priority
         if (w >= NOWN && guest_prio > 0) __builtin_amdgcn_s_setprio(2);
     }
-    __syncthreads();
+    barrier_publish<WLDS>();
 
     for (int blk = 0; blk < nblocks; ++blk) {
         const float* __restrict__ P = params + (size_t)blk * BLOCK_STRIDE;
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         stamp();            // QKV done
-        __syncthreads();    // K/V published; proj weights landed; buffer A free
+        barrier_publish<WLDS>();    // K/V published; proj weights landed; buffer A free
         stamp();
         if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         stamp();            // attention + proj done
-        __syncthreads();    // K/V and buffer B free; fc1 weights landed
+        barrier_publish<WLDS>();    // K/V and buffer B free; fc1 weights landed
         stamp();
         if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
         // ---- LN2 + MLP (residual add) ---------------------------------------------------------
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 }
             }
             stamp();            // fc1 done
-            __syncthreads();    // fc2 weights landed; buffer A free
+            barrier_publish<WLDS>();    // fc2 weights landed; buffer A free
             if (blk + 1 < nblocks) stage_tiles(Wa, P + BLOCK_STRIDE + O_WQKV, 9 * NC, w, NW, lane);   // next block's qkv
             stamp();
 #pragma unroll
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         stamp();            // MLP done
-        if constexpr (WLDS) __syncthreads();   // buffer B free; next qkv weights landed
+        if constexpr (WLDS) barrier_publish<true>();   // buffer B free; next qkv weights landed
         if constexpr (BAL) {
             if (w >= NOWN) {
 #pragma unroll

@@ -61,7 +61,6 @@ class OstrackDist:
                                                          len_z=g["len_z"], len_x=g["len_x"]))
         self._nat = None
         self._device = None
-        self._graphs = {}
         self.training = False
 
     # ---- nn.Module-like surface used by the reference's callers
@@ -83,8 +82,7 @@ class OstrackDist:
                                        f"{tuple(self._state[k].shape)}")
                 self._state[k] = v.astype(self._state[k].dtype, copy=True)
         if self._nat is not None:
-            self._nat.load_state_dict(self._state)
-            self._graphs.clear()
+            self._nat.load_state_dict(self._state)    # same buffers, new contents: captured graphs stay valid
         return _Incompatible(missing, unexpected)
 
     def cuda(self, device=None):
@@ -107,12 +105,12 @@ class OstrackDist:
         return self
 
     def reserve(self, max_batch: int):
-        """Re-size the native workspace (weights are re-uploaded)."""
+        """Re-size the native workspace (weights are re-uploaded).  Graphs captured from the old
+        workspace are invalidated: their ``launch`` raises instead of replaying over freed buffers."""
         self.max_batch = max_batch
         if self._nat is not None:
-            self._nat.close()
+            self._nat.close()       # invalidates every live native.Graph of this model
             self._nat = None
-            self._graphs.clear()
             self._native()
         return self
 
@@ -135,6 +133,11 @@ class OstrackDist:
         if z.shape[0] != B:
             raise ValueError(f"batch mismatch: z {tuple(z.shape)} vs x {tuple(x.shape)}")
         if B > self.max_batch:
+            nat = self._nat
+            if nat is not None and nat.live_graphs():
+                raise native.VtError(
+                    f"batch {B} exceeds max_batch={self.max_batch} and {nat.live_graphs()} captured graph(s) still use "
+                    f"this model's workspace: call reserve({B}) explicitly and re-capture them")
             self.reserve(B)
         o = self._native().forward(z.float().contiguous(), x.float().contiguous())
         return {"pred_boxes": o.pred_boxes.view(B, 1, 4), "score_map": o.score_map, "size_map": o.size_map,

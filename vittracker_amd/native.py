@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -132,12 +133,24 @@ class Outputs:
 
 
 class Graph:
-    def __init__(self, handle, keep):
+    """A captured step.  It holds its Model (the graph's kernels read the model's weight and workspace
+    buffers) and the tensors it was captured on; when the model is closed or re-sized the graph is
+    invalidated and ``launch`` raises instead of replaying kernels over freed memory."""
+
+    def __init__(self, handle, keep, model=None):
         self._h = handle
         self._keep = keep   # tensors the captured kernels read / write
+        self._model = model
+        self._valid = True
 
     def launch(self, stream=None):
+        if not self._valid:
+            raise VtError("this graph was captured from a model that has since been closed or re-sized "
+                          "(its weight / workspace buffers are gone): capture it again")
         _check(lib().vt_graph_launch(self._h, _stream(stream)), "vt_graph_launch")
+
+    def _invalidate(self):
+        self._valid = False
 
     def __del__(self):
         if getattr(self, "_h", None) and _lib is not None:
@@ -162,8 +175,37 @@ class Model:
         self.len_z, self.len_x, self.feat_sz, self.channels = [v.value for v in q]
         self.L = self.len_z + self.len_x
         self.max_batch = max_batch
+        self.template_size, self.search_size = template_size, search_size
+        self._graphs = weakref.WeakSet()
+
+    def live_graphs(self) -> int:
+        return sum(1 for g in self._graphs if g._valid)
+
+    # ---- argument checks (raw device pointers cross the C ABI: a wrong shape would read out of bounds)
+    def _check_crops(self, z, x):
+        B = z.shape[0]
+        tz, tx = self.template_size, self.search_size
+        if tuple(z.shape) != (B, 3, tz, tz) or tuple(x.shape) != (B, 3, tx, tx):
+            raise VtError(f"expected z (B,3,{tz},{tz}) and x (B,3,{tx},{tx}) with one batch size, got "
+                          f"{tuple(z.shape)} and {tuple(x.shape)}")
+        self._check_batch(B)
+        return B
+
+    def _check_batch(self, B):
+        if not (1 <= B <= self.max_batch):
+            raise VtError(f"batch {B} outside [1, max_batch={self.max_batch}]")
+
+    def _check_out(self, out, B):
+        F = self.feat_sz
+        want = {"score_map": (B, 1, F, F), "size_map": (B, 2, F, F), "offset_map": (B, 2, F, F), "pred_boxes": (B, 4),
+                "hann_boxes": (B, 4), "conf": (B,)}
+        for k, shp in want.items():
+            if tuple(getattr(out, k).shape) != shp:
+                raise VtError(f"output buffer {k} has shape {tuple(getattr(out, k).shape)}, want {shp}")
 
     def close(self):
+        for g in list(getattr(self, "_graphs", ())):
+            g._invalidate()
         if getattr(self, "_h", None) and _lib is not None:
             try:
                 _lib.vt_destroy(self._h)
@@ -198,24 +240,28 @@ class Model:
 
     # ---- whole step
     def forward(self, z, x, out: Outputs | None = None, stream=None) -> Outputs:
-        B = z.shape[0]
+        B = self._check_crops(z, x)
         out = out or Outputs(B, self.feat_sz, z.device)
+        self._check_out(out, B)
         st = out.struct()
         _check(lib().vt_forward(self._h, _ptr(z), _ptr(x), B, _stream(stream), C.byref(st)), "vt_forward")
         return out
 
     def capture(self, z, x, out: Outputs | None = None) -> tuple[Graph, Outputs]:
-        B = z.shape[0]
+        B = self._check_crops(z, x)
         out = out or Outputs(B, self.feat_sz, z.device)
+        self._check_out(out, B)
         st = out.struct()
         g = C.c_void_p()
         _check(lib().vt_graph_capture(self._h, _ptr(z), _ptr(x), B, C.byref(st), C.byref(g)), "vt_graph_capture")
-        return Graph(g, (z, x, out)), out
+        gr = Graph(g, (z, x, out), self)
+        self._graphs.add(gr)
+        return gr, out
 
     # ---- stages
     def stem(self, z, x, stream=None):
         import torch
-        B = z.shape[0]
+        B = self._check_crops(z, x)
         tok = torch.empty(B, self.L, self.channels, device=z.device)
         _check(lib().vt_stem(self._h, _ptr(z), _ptr(x), B, _stream(stream), _ptr(tok)), "vt_stem")
         return tok
@@ -223,15 +269,24 @@ class Model:
     def blocks(self, tokens, nblocks=-1, want_resid=False, stream=None, feat=None):
         import torch
         B = tokens.shape[0]
+        self._check_batch(B)
+        if tuple(tokens.shape) != (B, self.L, self.channels):
+            raise VtError(f"tokens must be (B,{self.L},{self.channels}), got {tuple(tokens.shape)}")
         if feat is None:
             feat = torch.empty(B, self.len_x, self.channels, device=tokens.device)
+        elif tuple(feat.shape) != (B, self.len_x, self.channels):
+            raise VtError(f"feat must be (B,{self.len_x},{self.channels}), got {tuple(feat.shape)}")
         resid = torch.empty_like(tokens) if want_resid else None
         _check(lib().vt_blocks(self._h, _ptr(tokens), B, nblocks, _stream(stream), _ptr(feat), _ptr(resid)), "vt_blocks")
         return (feat, resid) if want_resid else feat
 
     def head(self, feat, out: Outputs | None = None, stream=None) -> Outputs:
         B = feat.shape[0]
+        self._check_batch(B)
+        if tuple(feat.shape) != (B, self.len_x, self.channels):
+            raise VtError(f"feat must be (B,{self.len_x},{self.channels}), got {tuple(feat.shape)}")
         out = out or Outputs(B, self.feat_sz, feat.device)
+        self._check_out(out, B)
         st = out.struct()
         _check(lib().vt_head(self._h, _ptr(feat), B, _stream(stream), C.byref(st)), "vt_head")
         return out
@@ -246,10 +301,16 @@ class Model:
         if not (states.is_cuda and states.dtype == torch.float64 and states.is_contiguous()):
             raise VtError("states must be a contiguous (B,4) float64 tensor on the GPU")
         B, H, W, _ = frames.shape
+        if tuple(states.shape) != (B, 4):
+            raise VtError(f"states must be ({B},4) for {B} frames, got {tuple(states.shape)}")
         if out is None:
             out = torch.empty(B, 3, out_size, out_size, device=frames.device)
+        elif tuple(out.shape) != (B, 3, out_size, out_size):
+            raise VtError(f"crop output must be ({B},3,{out_size},{out_size}), got {tuple(out.shape)}")
         if resize_factor is None:
             resize_factor = torch.empty(B, dtype=torch.float64, device=frames.device)
+        elif tuple(resize_factor.shape) != (B,) or resize_factor.dtype != torch.float64 or not resize_factor.is_cuda:
+            raise VtError(f"resize_factor must be a ({B},) float64 tensor on the GPU")
         m3 = (C.c_float * 3)(*[float(v) for v in mean])
         s3 = (C.c_float * 3)(*[float(v) for v in std])
         _check(lib().vt_crop(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor),
@@ -259,13 +320,20 @@ class Model:
 
     def update_state(self, hann_boxes, resize_factor, states, search_size, H, W, margin=10, stream=None):
         B = states.shape[0]
+        if (tuple(states.shape) != (B, 4) or tuple(hann_boxes.shape) != (B, 4) or tuple(resize_factor.shape) != (B,)
+                or states.dtype != resize_factor.dtype or not states.is_cuda or not resize_factor.is_cuda):
+            raise VtError(f"update_state wants hann_boxes ({B},4) fp32, resize_factor ({B},) fp64 and states ({B},4) fp64 "
+                          f"on the GPU")
         _check(lib().vt_update_state(self._h, _ptr(hann_boxes), C.c_void_p(resize_factor.data_ptr()), search_size, H, W,
                                      margin, B, _stream(stream), C.c_void_p(states.data_ptr())), "vt_update_state")
         return states
 
     def cal_bbox(self, score, size, offset, stream=None):
         import torch
-        B = score.shape[0]
+        B, F = score.shape[0], self.feat_sz
+        if tuple(score.shape) != (B, 1, F, F) or tuple(size.shape) != (B, 2, F, F) or tuple(offset.shape) != (B, 2, F, F):
+            raise VtError(f"cal_bbox wants (B,1,{F},{F}), (B,2,{F},{F}), (B,2,{F},{F}) maps, got {tuple(score.shape)}, "
+                          f"{tuple(size.shape)}, {tuple(offset.shape)}")
         bbox = torch.empty(B, 4, device=score.device)
         mx = torch.empty(B, device=score.device)
         _check(lib().vt_cal_bbox(self._h, _ptr(score), _ptr(size), _ptr(offset), B, _stream(stream), _ptr(bbox), _ptr(mx)),

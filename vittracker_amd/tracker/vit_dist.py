@@ -17,6 +17,7 @@ from __future__ import annotations
 import os
 
 from ..host_ops import Preprocessor, clip_box, hann2d, sample_target
+from ..batched import check_params_geometry
 from ..model import build_ostrack_dist
 
 
@@ -60,6 +61,7 @@ class Vit_dist(BaseTracker):
         # motion constraint (:34); the same values drive the fused device-side decode
         self.output_window = hann2d(torch.tensor([self.feat_sz, self.feat_sz]).long(), centered=True).cuda()
         nat = self.network._native()
+        check_params_geometry(params, nat)
         nat.set_window(self.output_window.cpu().numpy())
 
         self.debug = getattr(params, "debug", 0)
