@@ -127,6 +127,60 @@ def import_reference():
     return model, config, box_ops, hann
 
 
+def import_reference_sample_target():
+    """lib/train/data/processing_utils.py loaded where it lies, with `cv2` replaced by a two-function
+    stand-in: ``copyMakeBorder(BORDER_CONSTANT)`` = constant zero ``np.pad`` (what OpenCV's constant
+    border does with the default value), ``resize`` raising (never reached on the ``output_sz=None``
+    return at :76).  Everything the fixtures pin -- crop side, banker's-rounded origin, the pad
+    formula with its ``+ 1`` quirk, the slice, the attention mask -- is executed by reference source."""
+    cv = types.ModuleType("cv2")
+    cv.BORDER_CONSTANT = 0
+
+    def copyMakeBorder(src, top, bottom, left, right, borderType, value=0):
+        assert borderType == cv.BORDER_CONSTANT
+        return np.pad(src, ((top, bottom), (left, right)) + ((0, 0),) * (src.ndim - 2), mode="constant")
+
+    def resize(*a, **k):
+        raise RuntimeError("cv2.resize is not available in this image: the resize step stays unpinned")
+
+    cv.copyMakeBorder, cv.resize = copyMakeBorder, resize
+    sys.modules["cv2"] = cv
+    for p in ("lib", "lib.train", "lib.train.data"):
+        if p not in sys.modules:
+            _pkg(p)
+    return _load("lib.train.data.processing_utils", "lib/train/data/processing_utils.py")
+
+
+CROP_IMAGE_HW = (36, 48)
+CROP_CASES = [  # (box [x, y, w, h], search_area_factor): inside, across each border and corner, fractional
+    ([14, 10, 8, 6], 2.0), ([-3, -2, 9, 9], 2.0), ([40, 28, 10, 9], 2.0), ([0, 0, 4, 4], 4.0), ([20.5, 13.5, 5, 3], 2.0),
+    ([44, 2, 6, 6], 2.0), ([2, 30, 7, 5], 2.0), ([3.25, 7.75, 2.5, 1.25], 4.0), ([10, 8, 30, 24], 1.5),
+    ([23.5, 17.5, 4, 4], 2.0), ([24.5, 18.5, 4, 4], 2.0),            # x.5 origins: round-half-even both ways
+    ([21, 15, 3, 3], 2.0), ([22, 16, 3, 3], 2.0), ([47, 35, 2, 2], 4.0), ([-6, 12, 5, 8], 3.0), ([12, -7, 8, 5], 3.0),
+    ([30, 20, 17.9, 15.9], 2.0), ([16, 12, 16, 12], 1.0), ([5.5, 4.5, 9, 9], 1.0), ([0, 0, 48, 36], 1.0),
+    ([11, 9, 1, 1], 1.0), ([11.5, 9.5, 1, 1], 2.0), ([35, 25, 12.5, 12.5], 2.0), ([1, 1, 0.6, 0.6], 4.0),
+]
+
+
+def make_crop_fixture(out_dir):
+    pu = import_reference_sample_target()
+    rs = np.random.RandomState(2024)
+    im = rs.randint(0, 256, CROP_IMAGE_HW + (3,)).astype(np.uint8)
+    res = {"image_seed": 2024, "image_hw": np.array(CROP_IMAGE_HW), "n": len(CROP_CASES),
+           "boxes": np.array([b for b, _ in CROP_CASES], dtype=np.float64), "factors": np.array([f for _, f in CROP_CASES])}
+    for i, (bb, f) in enumerate(CROP_CASES):
+        crop, mask, one = pu.sample_target(im, list(map(float, bb)), f, output_sz=None)     # (sic) order of :76
+        assert one == 1.0 and crop.shape[0] == crop.shape[1] == mask.shape[0]
+        res[f"crop_{i}"], res[f"mask_{i}"] = crop, mask
+    try:
+        pu.sample_target(im, [5.0, 5.0, 0.0, 0.0], 4.0, output_sz=None)
+        raise AssertionError("expected 'Too small bounding box.'")
+    except Exception as e:  # noqa: BLE001
+        res["too_small_message"] = str(e)
+    np.savez_compressed(os.path.join(out_dir, "ref_crop_geometry.npz"), **res)
+    print(f"ref_crop_geometry.npz: {len(CROP_CASES)} crops, sides {sorted({res[f'crop_{i}'].shape[0] for i in range(len(CROP_CASES))})}")
+
+
 def build_reference_model(model_mod, config_mod, geom: str):
     """G256: the shipped YAML as is.  G128: DATA.SEARCH.SIZE=128 so the head gets feat_sz=8
     (lib/models/layers/head.py:356) and the hard-coded 64/256-token pos-embeds
@@ -225,7 +279,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--out", default=HERE)
+    ap.add_argument("--only-crop", action="store_true", help="regenerate ref_crop_geometry.npz only")
     args = ap.parse_args()
+    if args.only_crop:
+        make_crop_fixture(args.out)
+        return
     torch.manual_seed(0)
     model_mod, config_mod, box_ops, hann_mod = import_reference()
     for geom, seed, B, with_acts in CASES:
@@ -249,6 +307,7 @@ def main():
     hw = {f"hann{n}": hann_mod.hann2d(torch.tensor([n, n]).long(), centered=True).numpy() for n in (8, 16, 20)}
     np.savez_compressed(os.path.join(args.out, "ref_hann.npz"), **hw)
     print("wrote clip_box / hann fixtures")
+    make_crop_fixture(args.out)
 
 
 if __name__ == "__main__":

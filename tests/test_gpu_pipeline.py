@@ -50,6 +50,44 @@ def test_device_crop_equals_host_crop(T, factor):
         np.testing.assert_array_equal(crops[b], want, err_msg=f"box {boxes[b]}")
 
 
+def test_device_crop_geometry_matches_reference_fixture():
+    """vt_crop's crop / pad geometry against the fixtures the REFERENCE's sample_target produced
+    (tests/golden/ref_crop_geometry.npz).  With out_size == crop side the fixed-point resize is the
+    identity, and with mean 0 / std 1 the output is pixel * (1/255): the uint8 crop is recovered exactly."""
+    import torch
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, "ref_crop_geometry.npz"))
+    H, W = int(g["image_hw"][0]), int(g["image_hw"][1])
+    im = np.random.RandomState(int(g["image_seed"])).randint(0, 256, (H, W, 3)).astype(np.uint8)
+    m = _nat(B=1)
+    fr = torch.from_numpy(im[None]).cuda()
+    for i in range(int(g["n"])):
+        want = g[f"crop_{i}"]
+        T = want.shape[0]
+        st = torch.tensor(g["boxes"][i][None], dtype=torch.float64).cuda()
+        crop, rf = m.crop(fr, st, float(g["factors"][i]), T, [0, 0, 0], [1, 1, 1])
+        assert float(rf[0]) == 1.0
+        got = np.rint(crop[0].cpu().numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+        np.testing.assert_array_equal(got, want, err_msg=f"case {i} box {g['boxes'][i]}")
+
+
+def test_device_crop_poisons_a_too_small_box_and_the_batched_tracker_raises():
+    import torch
+    m = _nat(B=2)
+    fr = torch.zeros(2, 32, 32, 3, dtype=torch.uint8, device="cuda")
+    st = torch.tensor([[5, 5, 0, 0], [5, 5, 8, 8]], dtype=torch.float64).cuda()
+    crop, rf = m.crop(fr, st, 4.0, 64, MEAN, STD)
+    assert torch.isnan(rf[0]) and torch.isnan(crop[0]).all() and not torch.isnan(crop[1]).any() and float(rf[1]) == 2.0
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.parameter import vit_dist as P
+    os.environ["VITTRACK_PRJ_DIR"] = REPO
+    p = P.parameters("vit_48_h32_g128")
+    p.allow_synthetic_weights, p.debug = True, 0
+    bt = BatchedVitTracker(p, 2)
+    with pytest.raises(Exception, match="Too small bounding box"):
+        bt.initialize(np.zeros((2, 32, 32, 3), np.uint8), [[5, 5, 0, 0], [5, 5, 8, 8]])
+
+
 def test_device_state_update_equals_host_tail():
     import torch
     from vittracker_amd.host_ops import clip_box

@@ -92,7 +92,7 @@ def test_depth_other_than_three(geom, depth):
     sd = synth.synth_state_dict(0, depth=depth, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
     z, x = synth.synth_inputs(5, 2, tz, tx)
     out = m.forward(torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda())
-    ref = onp.forward(sd, z, x)
+    ref = onp.forward(sd, z, x, depth=depth)
     for k in ("score_map", "size_map", "offset_map"):
         np.testing.assert_allclose(getattr(out, k).cpu().numpy(), ref[k], atol=2e-4, rtol=0, err_msg=k)
 

@@ -89,6 +89,34 @@ def test_sample_target_crop_and_pad(bb):
     np.testing.assert_array_equal(mask, rmask)
 
 
+def test_sample_target_geometry_matches_reference_fixture():
+    """Crop side, banker's-rounded origin, pad formula (with the reference's `+ 1` quirk), slice and
+    attention mask against fixtures produced by the reference's own sample_target
+    (tests/golden/make_golden.py::make_crop_fixture; the `output_sz=None` return, processing_utils.py:76)."""
+    from vittracker_amd.host_ops import sample_target
+    g = np.load(os.path.join(GOLDEN_DIR, "ref_crop_geometry.npz"))
+    H, W = g["image_hw"]
+    im = np.random.RandomState(int(g["image_seed"])).randint(0, 256, (int(H), int(W), 3)).astype(np.uint8)
+    for i in range(int(g["n"])):
+        crop, mask, one = sample_target(im, g["boxes"][i].tolist(), float(g["factors"][i]), output_sz=None)
+        np.testing.assert_array_equal(crop, g[f"crop_{i}"], err_msg=f"case {i} box {g['boxes'][i]}")
+        np.testing.assert_array_equal(mask, g[f"mask_{i}"], err_msg=f"case {i}")
+        assert one == 1.0
+    with pytest.raises(Exception, match=str(g["too_small_message"]).rstrip(".")):
+        sample_target(im, [5.0, 5.0, 0.0, 0.0], 4.0, output_sz=None)
+
+
+def test_resize_port_equals_cv2_when_cv2_is_available():
+    """The uint8 bilinear port (host_ops.resize_bilinear_u8, mirrored by vt_crop) against the real
+    cv2.resize -- runs only on a box that has OpenCV (this image does not: the resize stays unpinned)."""
+    cv2 = pytest.importorskip("cv2")
+    from vittracker_amd.host_ops import resize_bilinear_u8
+    rs = np.random.RandomState(5)
+    for (h, w), T in (((37, 53), 64), ((200, 200), 128), ((97, 97), 256), ((300, 300), 128), ((64, 64), 64)):
+        im = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        np.testing.assert_array_equal(resize_bilinear_u8(im, T, T), cv2.resize(im, (T, T)))
+
+
 def test_sample_target_resize_properties():
     """cv2 is absent here, so the bilinear port is checked through properties cv.resize has:
     identity at equal size, constants stay constant, exact 2x upsample of a horizontal ramp stays

@@ -102,7 +102,14 @@ class BatchedVitTracker:
         """frames: (B,H,W,3) uint8 (numpy, list of arrays or CUDA tensor); init_boxes: (B,4) [x,y,w,h]."""
         import torch
         fr = self._upload(frames)
-        self.states.copy_(torch.as_tensor(np.asarray(init_boxes, dtype=np.float64)))
+        boxes = np.asarray(init_boxes, dtype=np.float64)
+        if boxes.shape != (self.B, 4):
+            raise ValueError(f"init_boxes must be (B={self.B}, 4) [x, y, w, h]")
+        for f in (self.params.template_factor, self.params.search_factor):
+            side = np.ceil(np.sqrt(boxes[:, 2] * boxes[:, 3]) * f)
+            if not np.all(side >= 1):         # also catches NaN / negative sizes
+                raise Exception("Too small bounding box.")   # processing_utils.py:33-34
+        self.states.copy_(torch.as_tensor(boxes))
         self.nat.crop(fr, self.states, self.params.template_factor, self.params.template_size, self.mean, self.std,
                       out=self.z, resize_factor=self.rf)
         self.frame_id = 0

@@ -42,7 +42,17 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     const int b = blockIdx.y;
     const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
     int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
-    if (crop_sz < 1) crop_sz = 1;                 // the reference raises 'Too small bounding box.' here
+    if (!(crop_sz >= 1)) {
+        // The reference raises 'Too small bounding box.' here (processing_utils.py:33-34).  A kernel cannot
+        // raise: the crop and its resize factor are poisoned with NaN, so every box derived from them is NaN and
+        // the caller sees it (BatchedVitTracker checks user-supplied boxes on the host before they get here; boxes
+        // produced by vt_update_state are at least `margin` wide and never take this branch).
+        const int i0 = blockIdx.x * 256 + threadIdx.x;
+        if (i0 == 0) resize_factor[b] = __builtin_nan("");
+        if (i0 < T * T)
+            for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * T * T + i0] = __builtin_nanf("");
+        return;
+    }
     const int x1 = (int)rint(bx + 0.5 * bw - crop_sz * 0.5);     // Python round(): half to even
     const int y1 = (int)rint(by + 0.5 * bh - crop_sz * 0.5);
     const int x2 = x1 + crop_sz, y2 = y1 + crop_sz;
