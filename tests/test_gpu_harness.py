@@ -1,0 +1,78 @@
+"""GPU: tracking/test.py-style runs end to end on synthetic sequences (sequential plugin trackers vs the lock-step
+batched runner: the result files must be identical), run_video through the real plugin, and the deployment session
+against the reference-generated golden maps."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, REPO, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracker(tmp_path, monkeypatch, yaml_name="vit_48_h32_g128"):
+    from vittracker_amd.evaluation import Tracker
+    monkeypatch.setenv("VITTRACK_SAVE_DIR", str(tmp_path))
+    monkeypatch.setenv("VITTRACK_PRJ_DIR", REPO)
+    t = Tracker("vit_dist", yaml_name, "synthetic")
+    get = t.get_parameters
+
+    def params():
+        p = get()
+        p.allow_synthetic_weights = True
+        return p
+    t.get_parameters = params
+    return t
+
+
+def test_sequential_and_batched_runs_write_identical_box_files(tmp_path, monkeypatch):
+    from vittracker_amd.evaluation import get_dataset
+    from vittracker_amd.evaluation.running import run_dataset, run_dataset_batched
+    ds = get_dataset("synthetic:5x6")                       # ragged lengths 6, 8, 10, 6, 8
+    ts = _tracker(tmp_path / "seq", monkeypatch)
+    run_dataset(ds, [ts], debug=False, threads=0)
+    tb = _tracker(tmp_path / "bat", monkeypatch)
+    run_dataset_batched(ds, tb, batch=4)                    # groups of 4 + 1
+    for s in ds:
+        a = open(os.path.join(ts.results_dir, s.name + ".txt")).read()
+        b = open(os.path.join(tb.results_dir, s.name + ".txt")).read()
+        assert a == b and len(a.splitlines()) == len(s), s.name
+        tl = open(os.path.join(tb.results_dir, s.name + "_time.txt")).read().splitlines()
+        assert len(tl) == len(s) and all(float(v) > 0 for v in tl)
+    # the target really is tracked on these textures? no: weights are synthetic -- only consistency is asserted
+
+
+def test_run_video_through_the_plugin(tmp_path, monkeypatch):
+    from vittracker_amd.evaluation.data import synthetic_sequence
+    t = _tracker(tmp_path, monkeypatch, "vit_48_h32_noKD")
+    seq = synthetic_sequence("clip", 6)
+    np.save(tmp_path / "clip.npy", np.stack(seq.frames))
+    box0 = seq.init_info()["init_bbox"]
+    boxes = t.run_video(str(tmp_path / "clip.npy"), optional_box=box0, save_results=True)
+    assert len(boxes) == 6 and all(isinstance(v, int) for v in boxes[1])
+    rows = open(os.path.join(t.results_dir, "video_clip.txt")).read().splitlines()
+    assert len(rows) == 6 and rows[1] == "\t".join(str(v) for v in boxes[1])
+    # same boxes as the sequence loop (which also feeds RGB arrays here)
+    out = t.run_sequence(seq)
+    assert [[int(v) for v in b] for b in out["target_bbox"][1:]] == boxes[1:]
+
+
+def test_deploy_session_matches_reference_golden_maps():
+    from vittracker_amd import deploy
+    g, sd, z, x = load_case(os.path.join(GOLDEN_DIR, "ref_G256_s1_b1.npz"))
+    sess = deploy.VitTrackSession(sd)
+    assert [i.name for i in sess.get_inputs()] == ["template", "search"]
+    o1, o2, o3 = sess.run(None, {"template": z, "search": x})
+    assert o1.shape == (1, 1, 16, 16) and o2.shape == (1, 2, 16, 16) and o3.shape == (1, 2, 16, 16)
+    np.testing.assert_allclose(o1, g["score_map"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(o2, g["size_map"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(o3, g["offset_map"], atol=1e-4, rtol=0)
+    (only3,) = sess.run(["output3"], {"template": z, "search": x})
+    np.testing.assert_array_equal(only3, o3)
+    with pytest.raises(ValueError, match="invalid dimensions"):
+        sess.run(None, {"template": x, "search": x})
+    with pytest.raises(ValueError, match="missing"):
+        sess.run(None, {"template": z})
+    with pytest.raises(ValueError, match="Invalid output name"):
+        sess.run(["output4"], {"template": z, "search": x})
