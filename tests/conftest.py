@@ -40,3 +40,18 @@ def native():
     """The C-ABI library (loads everywhere; compute calls need a GPU)."""
     from vittracker_amd import native as nat
     return nat
+
+
+def vitb_golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "ref_vitb_*.npz")))
+
+
+def load_vitb_case(path):
+    """(fixture, state dict, z, x) of a ViT-Base golden file; weights / inputs regenerated from the seed."""
+    from vittracker_amd import synth
+    g = dict(np.load(path, allow_pickle=False))
+    seed, B = int(g["seed"]), int(g["B"])
+    sd = synth.synth_vitb_state_dict(seed)
+    assert synth.state_checksum(sd) == str(g["state_checksum"]), "synth_vitb_state_dict drifted from the fixture generator"
+    z, x = synth.synth_inputs(seed, B, 128, 256)
+    return g, sd, z, x

@@ -77,3 +77,29 @@ def test_mac_counts_match_survey():
     assert (g256["stem"], g256["blocks"], g256["head"], g256["total"]) == (13271040, 56033280, 15266816, 84571136)
     g128 = onp.macs_per_frame(64, 128)
     assert (g128["stem"], g128["blocks"], g128["head"], g128["total"]) == (3317760, 8478720, 3816704, 15613184)
+
+
+# ---------------------------------------------------------------------------------------- ViT-Base (config 4)
+def test_vitb_torch_oracle_matches_reference():
+    """oracle/vitb_oracle_torch.py against the outputs and activations of the reference's own build_ostrack model
+    (tests/golden/make_golden_vitb.py).  fp32 both sides; different op order (conv vs unfold etc.) -> ~1e-5."""
+    import torch
+    from conftest import load_vitb_case, vitb_golden_files
+    from oracle import vitb_oracle_torch as ob
+    files = vitb_golden_files()
+    assert files, "ViT-Base fixtures missing"
+    for path in files:
+        g, sd, z, x = load_vitb_case(path)
+        m = ob.build_from_state(sd)
+        acts = {}
+        with torch.no_grad():
+            out = m(torch.from_numpy(z), torch.from_numpy(x), acts)
+        for k in ("score_map", "size_map", "offset_map", "pred_boxes"):
+            np.testing.assert_allclose(out[k].numpy(), g[k], atol=5e-5, rtol=0, err_msg=k)
+        assert min(g["margin_raw"].min(), g["margin_hann"].min()) > 0.03
+        if "act_norm" in g:
+            rows = g["act_rows"]
+            for k in ["tokens", "norm"] + [f"block{i}" for i in range(12)]:
+                np.testing.assert_allclose(acts[k][:1, rows].numpy(), g["act_" + k], atol=2e-4, rtol=0, err_msg=k)
+    mac = ob.macs_per_frame()
+    assert abs(sum(mac.values()) - 30.9e9) / 30.9e9 < 0.02          # SURVEY 8(d): ~30.9 GMAC / frame

@@ -99,3 +99,63 @@ def state_checksum(sd: dict) -> str:
         h.update(k.encode())
         h.update(np.ascontiguousarray(sd[k]).tobytes())
     return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------- ViT-Base (BASELINE config 4)
+def synth_vitb_state_dict(seed: int = 0, C: int = 768, depth: int = 12, heads: int = 12, head_ch: int = 256,
+                          len_z: int = 64, len_x: int = 256, patch: int = 16, mlp_ratio: int = 4) -> dict:
+    """Seeded synthetic weights in the OSTrack ``ckpt['net']`` key layout (``backbone.*`` = VisionTransformer,
+    lib/models/ostrack/vit.py:94-139 after ``finetune_track``, lib/models/ostrack/base_backbone.py:37-108;
+    ``box_head.*`` = CenterPredictor(inplanes=768, channel=256), lib/models/layers/head.py:98-128).
+    ``backbone.pos_embed`` / ``backbone.cls_token`` exist in the reference module but are unused by its forward."""
+    rs = np.random.RandomState(50_000 + seed)
+    sd: dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rs.standard_normal(shape) * std).astype(np.float32)
+
+    def uniform(shape, lo, hi):
+        return rs.uniform(lo, hi, shape).astype(np.float32)
+
+    def bn(prefix, n):
+        sd[prefix + ".weight"] = uniform((n,), 0.8, 1.2)
+        sd[prefix + ".bias"] = normal((n,), 0.1)
+        sd[prefix + ".running_mean"] = normal((n,), 0.1)
+        sd[prefix + ".running_var"] = uniform((n,), 0.5, 1.5)
+        sd[prefix + ".num_batches_tracked"] = np.array(1234, dtype=np.int64)
+
+    b = "backbone."
+    sd[b + "cls_token"] = np.zeros((1, 1, C), np.float32)
+    sd[b + "pos_embed"] = np.zeros((1, 197, C), np.float32)
+    sd[b + "pos_embed_z"] = normal((1, len_z, C), 0.1)
+    sd[b + "pos_embed_x"] = normal((1, len_x, C), 0.1)
+    sd[b + "patch_embed.proj.weight"] = normal((C, 3, patch, patch), (1.0 / (3 * patch * patch)) ** 0.5)
+    sd[b + "patch_embed.proj.bias"] = normal((C,), 0.1)
+    H, hd = C * mlp_ratio, C // heads
+    for i in range(depth):
+        p = f"{b}blocks.{i}."
+        sd[p + "norm1.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+        sd[p + "norm1.bias"] = normal((C,), 0.05)
+        # per-head logits q.k / sqrt(hd) get a spread of ~1.3: softmax neither flat nor one-hot
+        sd[p + "attn.qkv.weight"] = normal((3 * C, C), 1.15 / C ** 0.5)
+        sd[p + "attn.qkv.bias"] = normal((3 * C,), 0.1)
+        sd[p + "attn.proj.weight"] = normal((C, C), 0.5 / C ** 0.5)
+        sd[p + "attn.proj.bias"] = normal((C,), 0.05)
+        sd[p + "norm2.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+        sd[p + "norm2.bias"] = normal((C,), 0.05)
+        sd[p + "mlp.fc1.weight"] = normal((H, C), 1.0 / C ** 0.5)
+        sd[p + "mlp.fc1.bias"] = normal((H,), 0.1)
+        sd[p + "mlp.fc2.weight"] = normal((C, H), 0.5 / H ** 0.5)
+        sd[p + "mlp.fc2.bias"] = normal((C,), 0.05)
+    sd[b + "norm.weight"] = (1.0 + rs.standard_normal(C) * 0.1).astype(np.float32)
+    sd[b + "norm.bias"] = normal((C,), 0.05)
+    for t in ("ctr", "offset", "size"):
+        for i, (cin, cout) in enumerate(head_channels(C, head_ch)):
+            sd[f"box_head.conv{i + 1}_{t}.0.weight"] = normal((cout, cin, 3, 3), (2.0 / (cin * 9)) ** 0.5)
+            sd[f"box_head.conv{i + 1}_{t}.0.bias"] = normal((cout,), 0.1)
+            bn(f"box_head.conv{i + 1}_{t}.1", cout)
+        nout = 1 if t == "ctr" else 2
+        std = {"ctr": 0.45, "offset": 0.15, "size": 0.3}[t]
+        sd[f"box_head.conv5_{t}.weight"] = normal((nout, head_ch // 8, 1, 1), std)
+        sd[f"box_head.conv5_{t}.bias"] = normal((nout,), 0.1)
+    return sd
