@@ -1,0 +1,96 @@
+"""bench.py --config vitb: BASELINE config 4 -- OSTrack-256 style ViT-Base (embed 768, 12 heads, depth 12, 256 px search /
+128 px template, CENTER head 256 ch) on 1 x MI355X, bf16 MFMA, batch 256, hipGraph replay, inputs resident in HBM."""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+PEAK_BF16_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak
+METRIC = "track() frames/sec per GPU, OSTrack-256 ViT-Base (768 / 12 heads / depth 12), 256px search / 128px template"
+
+
+def macs():
+    C, L, Lx, depth, W, patch = 768, 320, 256, 12, 256, 16
+    return {"patch": L * 3 * patch * patch * C, "blocks": depth * (12 * C * C * L + 2 * L * L * C),
+            "head": Lx * (3 * 9 * (C * W + W * W // 2 + W * W // 8 + W * W // 32) + 5 * W // 8)}
+
+
+def run(a):
+    import torch
+    from vittracker_amd import native, synth
+    if a.gpus != 1:
+        raise SystemExit("--config vitb is a single-GPU configuration (BASELINE config 4)")
+    torch.cuda.set_device(0)
+    B = a.batch
+    sd = synth.synth_vitb_state_dict(26)
+    m = native.Model(128, 256, channels=768, heads=12, depth=12, head_channels=256, max_batch=B)
+    m.load_state_dict(sd)
+    z, x = synth.synth_inputs(0, B, 128, 256)
+    zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+    out = native.Outputs(B, 16, "cuda")
+    graph, _ = m.capture(zd, xd, out)
+    s = torch.cuda.Stream()
+    # ---- correctness gate in the timed configuration: first frames = a reference fixture's inputs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_vitb_s26_b2.npz"))
+    zg, xg = synth.synth_inputs(26, 2, 128, 256)
+    nb = min(2, B)
+    zs, xs = zd[:nb].clone(), xd[:nb].clone()
+    zd[:nb].copy_(torch.from_numpy(zg[:nb])); xd[:nb].copy_(torch.from_numpy(xg[:nb]))
+    torch.cuda.synchronize()
+    graph.launch(s); s.synchronize()
+    errs = {k: float(np.abs(getattr(out, k)[:nb].cpu().numpy() - g[k][:nb]).max()) for k in ("score_map", "size_map", "offset_map")}
+    errs["pred_boxes"] = float(np.abs(out.pred_boxes[:nb].cpu().numpy() - g["pred_boxes"][:nb, 0]).max())
+    if not (errs["score_map"] < 3e-2 and errs["size_map"] < 3e-2 and errs["offset_map"] < 6e-2 and errs["pred_boxes"] < 1e-2):
+        raise SystemExit(f"bench.py --config vitb: the timed configuration disagrees with the reference fixture: {errs}")
+    zd[:nb].copy_(zs); xd[:nb].copy_(xs)
+    torch.cuda.synchronize()
+
+    def replay(n):
+        with torch.cuda.stream(s):
+            for _ in range(n):
+                graph.launch(s)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:       # time-based pre-warm
+        replay(2); s.synchronize()
+    replay(a.warmup); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    replay(a.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mac = macs()
+    flop_frame = 2 * sum(mac.values())
+    value = B * a.steps / elapsed
+    line = {"metric": METRIC, "value": round(value, 1), "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"OSTrack-256 ViT-Base (C 768, 12 heads, depth 12, patch 16, CENTER head 256), batch {B}, "
+                                   f"hipGraph replay, N(0,1) crops, seeded synthetic weights; bf16 operands, f32 accumulate / residual",
+                       "batch_per_gpu": B, "global_batch": B, "parallelism": "1 GPU"},
+            "checked": True, "check": {"fixture": "ref_vitb_s26_b2.npz", "frames": nb, "max_abs_err": {k: float(f"{v:.2e}") for k, v in errs.items()}},
+            "frac_bf16_peak_whole_step": round(value * flop_frame / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if not a.no_extra:
+        # dominant kernel: the fc1 / fc2 GEMMs (K or N = 3072): time one fc1-shaped launch sequence through the stage API
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tok = m.stem(zd, xd)
+        feat = torch.empty(B, 256, 768, device="cuda")
+        torch.cuda.synchronize()
+        iters = max(3, a.steps // 4)
+        with torch.cuda.stream(s):
+            m.blocks(tok, stream=s, feat=feat)
+            e0.record()
+            for _ in range(iters):
+                m.blocks(tok, stream=s, feat=feat)
+            e1.record()
+        e1.synchronize()
+        t_blocks = e0.elapsed_time(e1) * 1e3 / iters
+        flop_blocks = 2 * mac["blocks"] * B
+        ach = flop_blocks / (t_blocks * 1e-6) / 1e12
+        line["roofline"] = {"kernel": "transformer blocks (12 x {LN, qk / v GEMM, attention, proj GEMM, LN, fc1 GEMM, fc2 GEMM})",
+                            "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "flop_per_launch": flop_blocks,
+                            "avg_launch_us": round(t_blocks, 1)}
+    print(json.dumps(line), flush=True)

@@ -1,0 +1,120 @@
+// vb_attn.h -- multi-head self-attention over the joint (template + search) token set, bf16 MFMA, gfx950.
+//
+// lib/models/ostrack/vit.py:51-66: softmax(q k^T * d^-0.5) v per head (12 heads x 64 at ViT-Base), all L = 320 keys,
+// no mask.  q arrives pre-scaled (the scale, a power of two, is folded into W_q / b_q at load time).
+//
+// One workgroup = one (frame, head).  K (L x 64) and V^T (64 x L, written transposed by the qkv GEMM) are staged once
+// into LDS by LDS-DMA as 16-row x 32-k sub-tiles (the GEMM's st_16x32 image, conflict-free ds_read_b128); the four waves
+// then walk the L / 16 query tiles.  Per query tile:
+//     S^T = K q^T          keys on the MFMA rows: a softmax row is 4 * L/16 registers of one lane + two permlane swaps
+//     P   = exp2((S - max) * log2 e), row sum in f32
+//     O^T = V^T P^T        P^T's B-operand image is S^T's own registers (rounded to bf16): no LDS round trip
+// The L x L score matrix never exists in memory.  Key order inside a 32-key chunk is permuted identically on both
+// sides (rows of the K image are stored as key = 32c + 8(i >> 2) + (i & 3) [+ 4 for the odd tile]), so that the eight
+// P values a lane owns after the two S^T tiles of a chunk are exactly keys 32c + 8q + {0..7}: V^T is read in natural order.
+#pragma once
+#include "vb_gemm.h"
+
+namespace vba {
+
+using vbg::bf16;
+using vbg::bf16x4;
+using vbg::bf16x8;
+
+template <int L, int HD>
+struct Geo {
+    static constexpr int NT = L / 16;              // key / query tiles
+    static constexpr int NC = L / 32;              // 32-key chunks
+    static constexpr int KS = HD / 32;             // k-steps of q.k (d = 64 -> 2)
+    static constexpr int DT = HD / 16;             // output d tiles
+    static constexpr int K_SUB = NT * KS;          // 1 KiB sub-tiles of the K image
+    static constexpr int V_SUB = DT * NC;          // ... of the V^T image
+    static constexpr int LDS_BYTES = (K_SUB + V_SUB) * 1024;
+};
+
+// qk: [M][2 C] bf16 (q | k), vt: [B][C][L] bf16, out: [M][C] bf16;  C = heads * HD.  grid = B * heads, 256 threads.
+template <int L, int HD>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
+                                                   bf16* __restrict__ out, int heads) {
+    using G = Geo<L, HD>;
+    static_assert(L % 32 == 0 && HD % 32 == 0, "tile shapes");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kimg = smem;
+    char* Vimg = smem + G::K_SUB * 1024;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f = blockIdx.x / heads, h = blockIdx.x - f * heads, C = heads * HD;
+    const bf16* qf = qk + (size_t)f * L * 2 * C + h * HD;          // q rows of this frame / head
+    const bf16* kf = qf + C;
+    const bf16* vf = vt + ((size_t)f * C + h * HD) * L;
+
+    // ---- stage K (rows permuted) and V^T
+    const int pl = vbg::swz_byte(lane * 16), prow = pl >> 6, pk = (pl & 63) >> 1;
+    for (int s = w; s < G::K_SUB; s += 4) {
+        const int t = s / G::KS, ks = s - t * G::KS;
+        const int key = 32 * (t >> 1) + 8 * (prow >> 2) + (prow & 3) + 4 * (t & 1);
+        vbg::glds16(kf + (size_t)key * 2 * C + ks * 32 + pk, Kimg + s * 1024 + lane * 16);
+    }
+    for (int s = w; s < G::V_SUB; s += 4) {
+        const int dt = s / G::NC, c = s - dt * G::NC;
+        vbg::glds16(vf + (size_t)(dt * 16 + prow) * L + c * 32 + pk, Vimg + s * 1024 + lane * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int l15 = lane & 15, q = lane >> 4;
+    const int fr = vbg::swz_byte(l15 * 64 + q * 16);
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int qt = w; qt < G::NT; qt += 4) {
+        // the K / V^T fragments do not depend on the query tile: without this the compiler hoists all 80 ds_reads
+        // (320 VGPRs) out of the loop and spills them
+        int frq = fr;
+        asm volatile("" : "+v"(frq));
+        bf16x8 qfrag[G::KS];
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+            qfrag[ks] = *reinterpret_cast<const bf16x8*>(qf + (size_t)(qt * 16 + l15) * 2 * C + ks * 32 + q * 8);
+        f4 S[G::NT];
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {
+            S[t] = splat4(0.f);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks)
+                S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Kimg + (t * G::KS + ks) * 1024 + frq),
+                                                               qfrag[ks], S[t], 0, 0, 0);
+        }
+        float mx = hmax4(S[0]);
+#pragma unroll
+        for (int t = 1; t < G::NT; ++t) mx = fmaxf(mx, hmax4(S[t]));
+        mx = quad_max(mx);
+        const float mb = mx * LOG2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < G::NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(S[t][r], LOG2E, -mb));
+                S[t][r] = p;
+                sum += p;
+            }
+        }
+        sum = quad_sum(sum);
+        f4 O[G::DT];
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) O[dt] = splat4(0.f);
+#pragma unroll
+        for (int c = 0; c < G::NC; ++c) {
+            const bf16x4 lo = vbg::to_bf16x4(S[2 * c]), hi = vbg::to_bf16x4(S[2 * c + 1]);
+            const bf16x8 p = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt)
+                O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Vimg + (dt * G::NC + c) * 1024 + frq), p,
+                                                                O[dt], 0, 0, 0);
+        }
+        const float inv = 1.0f / sum;
+        bf16* o = out + (size_t)(f * L + qt * 16 + l15) * C + h * HD + q * 4;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = vbg::to_bf16x4(O[dt] * splat4(inv));
+    }
+}
+
+}  // namespace vba

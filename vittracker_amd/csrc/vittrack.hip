@@ -15,6 +15,7 @@
 #include <utility>
 #include <vector>
 
+#include "vb_api.h"
 #include "vt_blocks.h"
 #include "vt_head.h"
 #include "vt_stem.h"
@@ -57,6 +58,7 @@ constexpr int STEM_CH[5] = {3, 6, 12, 24, 48};
 }  // namespace
 
 struct vt_model {
+    VbModel* vb = nullptr;           // ViT-Base path (channels = 768): backbone + head towers live in vitb.hip
     vt_config cfg{};
     int len_z = 0, len_x = 0, L = 0, F = 0, Fz = 0;
     bool weights_loaded = false;
@@ -357,6 +359,20 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
 }
 
+// ViT-Base: towers + conv5 in vitb.hip, then the same decode kernel (first-index argmax, raw and Hann-windowed)
+int run_head_vitb(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o) {
+    float* score = (o && o->score_map) ? o->score_map : m->score.p;
+    float* size = (o && o->size_map) ? o->size_map : m->size.p;
+    float* offset = (o && o->offset_map) ? o->offset_map : m->offset.p;
+    float* pred = (o && o->pred_boxes) ? o->pred_boxes : m->pred.p;
+    float* hann = (o && o->hann_boxes) ? o->hann_boxes : m->hann.p;
+    float* conf = (o && o->conf) ? o->conf : m->conf.p;
+    std::string err;
+    int rc = vb::head(m->vb, feat, B, st, score, size, offset, &err);
+    if (rc) return fail(rc, err);
+    return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
+}
+
 // ------------------------------------------------------------------------------------ self test
 __global__ void mfma_selftest_kernel(const float* A, const float* Bm, float* D) {
     // A (16x16 k-chunk as operand image source: A[i][k]), B[k][j]; D[i][j] = sum_k A[i][k] B[k][j]
@@ -399,6 +415,31 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ sr
     }
 }
 
+// ViT-Base model: the shared part of vt_model is the output scratch, the window and the capture stream
+int create_vitb(const vt_config* cfg, vt_model** out) {
+    std::string err;
+    VbModel* vbm = nullptr;
+    int rc = vb::create(cfg, &vbm, &err);
+    if (rc) return fail(rc, err);
+    vt_model* m = new vt_model();
+    m->vb = vbm;
+    m->cfg = *cfg;
+    m->F = cfg->search_size / 16;
+    m->Fz = cfg->template_size / 16;
+    m->len_x = m->F * m->F;
+    m->len_z = m->Fz * m->Fz;
+    m->L = m->len_x + m->len_z;
+    const size_t B = (size_t)cfg->max_batch;
+    auto A = [&](DevBuf& d, size_t n) { if (!rc) rc = d.alloc(n); };
+    A(m->score, B * m->len_x); A(m->size, B * 2 * m->len_x); A(m->offset, B * 2 * m->len_x);
+    A(m->pred, B * 4); A(m->hann, B * 4); A(m->conf, B);
+    if (!rc) rc = upload(m->window, hann2d(m->F));
+    if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
+    if (rc) { vt_destroy(m); return rc; }
+    *out = m;
+    return VT_OK;
+}
+
 }  // namespace
 
 // =========================================================================================== ABI
@@ -409,10 +450,11 @@ const char* vt_version(void) { return "vittrack-hip 0.1 (gfx950)"; }
 
 int vt_create(const vt_config* cfg, vt_model** out) {
     if (!cfg || !out) return fail(VT_ERR_ARG, "null argument");
+    if (cfg->channels == 768) return create_vitb(cfg, out);
     if (cfg->channels != 48 || cfg->heads != 1 || cfg->head_channels != 32 || cfg->stride != 16)
         return fail(VT_ERR_ARG,
                     "unsupported model: this build implements CHANNELS=48, HEADS=1, HEAD.NUM_CHANNELS=32, STRIDE=16 "
-                    "(the shipped vit_48_h32 config); got channels=" + std::to_string(cfg->channels) + " heads=" +
+                    "(the shipped vit_48_h32 config) and CHANNELS=768, HEADS=12, HEAD.NUM_CHANNELS=256 (ViT-Base OSTrack-256); got channels=" + std::to_string(cfg->channels) + " heads=" +
                         std::to_string(cfg->heads) + " head_channels=" + std::to_string(cfg->head_channels));
     const bool g128 = cfg->template_size == 64 && cfg->search_size == 128;
     const bool g256 = cfg->template_size == 128 && cfg->search_size == 256;
@@ -517,6 +559,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
 
 void vt_destroy(vt_model* m) {
     if (!m) return;
+    if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat,
@@ -538,6 +581,12 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     for (int i = 0; i < n; ++i)
         if (tensors[i].name && tensors[i].data) tm[tensors[i].name] = {tensors[i].data, tensors[i].numel};
     int rc;
+    if (m->vb) {
+        std::string err;
+        if ((rc = vb::load_weights(m->vb, tm, &err))) return fail(rc, err);
+        m->weights_loaded = true;
+        return VT_OK;
+    }
     const int C = 48;
     // ---- stem (patch_embed.net.{0,2,4,6}.{c,bn})
     for (int i = 0; i < 4; ++i) {
@@ -637,6 +686,11 @@ int vt_stem(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!z_dev || !x_dev || !tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb) {
+        std::string err;
+        rc = vb::stem(m->vb, z_dev, x_dev, B, static_cast<hipStream_t>(stream), tokens_dev, &err);
+        return rc ? fail(rc, err) : VT_OK;
+    }
     return run_stem(m, z_dev, x_dev, B, static_cast<hipStream_t>(stream), tokens_dev);
 }
 
@@ -645,6 +699,11 @@ int vt_blocks(vt_model* m, const float* tokens_dev, int32_t B, int32_t nblocks, 
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb) {
+        std::string err;
+        rc = vb::blocks(m->vb, tokens_dev, B, nblocks, static_cast<hipStream_t>(stream), feat_dev, resid_dev, &err);
+        return rc ? fail(rc, err) : VT_OK;
+    }
     return run_blocks(m, tokens_dev, B, nblocks, static_cast<hipStream_t>(stream), feat_dev ? feat_dev : m->feat.p,
                       resid_dev);
 }
@@ -653,6 +712,7 @@ int vt_head(vt_model* m, const float* feat_dev, int32_t B, void* stream, const v
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!feat_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb) return run_head_vitb(m, feat_dev, B, static_cast<hipStream_t>(stream), out);
     return run_head(m, feat_dev, B, static_cast<hipStream_t>(stream), out);
 }
 
@@ -661,6 +721,12 @@ int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, v
     if (rc) return rc;
     if (!z_dev || !x_dev) return fail(VT_ERR_ARG, "null device pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (m->vb) {
+        std::string err;
+        if ((rc = vb::stem(m->vb, z_dev, x_dev, B, st, nullptr, &err))) return fail(rc, err);
+        if ((rc = vb::blocks(m->vb, nullptr, B, -1, st, nullptr, nullptr, &err))) return fail(rc, err);
+        return run_head_vitb(m, nullptr, B, st, out);
+    }
     if ((rc = run_stem(m, z_dev, x_dev, B, st, m->tokens.p))) return rc;
     if ((rc = run_blocks(m, m->tokens.p, B, -1, st, m->feat.p, nullptr))) return rc;
     return run_head(m, m->feat.p, B, st, out);
@@ -717,7 +783,7 @@ int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_
     // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
     // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
     int nch = m->graph_chains;   // default 1
-    nch = std::max(1, std::min({nch, 4, (int)B}));
+    nch = m->vb ? 1 : std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
