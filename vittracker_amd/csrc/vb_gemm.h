@@ -76,12 +76,6 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f4 v) {
     return bf16x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-__device__ __forceinline__ float gelu_exact(float u) {
-    // nn.GELU() (erf form).  erff here, not the A&S polynomial of the f32 path: the result is rounded to bf16 anyway,
-    // but the polynomial's copysign / rcp sequence is no cheaper than libm's erff at this accuracy need
-    return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f));
-}
-
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     static_assert(WM * WN == NWAVES, "8 waves");
@@ -95,42 +89,44 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
 
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / WN, wn = w % WN;
-    // ---- XCD-aware tile order
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM, nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int grp = blockIdx.y;
     const bf16* __restrict__ X = a.X + grp * a.gX;
     const bf16* __restrict__ W = a.W + grp * a.gW;
     const float* __restrict__ bias = a.bias + grp * a.gBias;
 
+    // ---- XCD-aware tile order: virtual block id -> tile
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int tm = t / tiles_n;
+        m0 = tm * BM;
+        n0 = (t - tm * tiles_n) * BN;
+    };
     // ---- per-lane DMA sources of this wave's sub-tiles (element offsets at k-tile 0)
     const int pl = swz_byte(lane * 16), prow = pl >> 6, pk = (pl & 63) >> 1;     // row in sub-tile, k element in sub-tile
     unsigned src_off[NS];
+    auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int s = w + NWAVES * i;
-        if (i < NSX) {
-            int m = m0 + (s >> 1) * 16 + prow;
-            m = m < a.M ? m : a.M - 1;                                          // rows past M: a valid row, result unused
-            unsigned base;
-            if constexpr (AMODE == A_CONV) {
-                const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                base = (unsigned)(((b * P + y) * P + x) * a.C);
+        for (int i = 0; i < NS; ++i) {
+            const int s = w + NWAVES * i;
+            if (i < NSX) {
+                int m = m0 + (s >> 1) * 16 + prow;
+                m = m < a.M ? m : a.M - 1;                                          // rows past M: a valid row, result unused
+                unsigned base;
+                if constexpr (AMODE == A_CONV) {
+                    const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                    base = (unsigned)(((b * P + y) * P + x) * a.C);
+                } else {
+                    base = (unsigned)m * (unsigned)a.K;
+                }
+                src_off[i] = base + (s & 1) * 32 + pk;
             } else {
-                base = (unsigned)m * (unsigned)a.K;
+                const int sw = s - SX;
+                src_off[i] = (unsigned)(n0 + (sw >> 1) * 16 + prow) * (unsigned)a.K + (sw & 1) * 32 + pk;   // W rows are padded to BN
             }
-            src_off[i] = base + (s & 1) * 32 + pk;
-        } else {
-            const int sw = s - SX;
-            src_off[i] = (unsigned)(n0 + (sw >> 1) * 16 + prow) * (unsigned)a.K + (sw & 1) * 32 + pk;   // W rows are padded to BN
         }
-    }
+    };
     auto stage = [&](int kt, char* buf) {
         unsigned kx;     // element offset of k-tile kt along an X row
         if constexpr (AMODE == A_CONV) {
@@ -148,99 +144,139 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     };
 
     f4 acc[TN][TM];
+    const int q4 = (lane >> 4) * 4, l15 = lane & 15;
+    // Normal tiles: lane holds n = nb + 4q + {0..3} of token m = mb + (lane & 15).
+    auto epilogue = [&](int m0, int n0) {
+        if constexpr (EPI == EPI_VT) {
+            // swapped tile: lane holds tokens m = mb + 4q + {0..3} of feature n = nb + (lane & 15)
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i) {
+                const int n = n0 + wn * TN * 16 + i * 16 + l15;
+                const float b = bias[n];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = splat4(0.f);
+                for (int j = 0; j < TM; ++j) {
+                    const int m = m0 + (wm * TM + j) * 16 + q4;
+                    if (m < a.M) {     // M is a multiple of 4 (L is)
+                        const int f = m / a.L, t = m - f * a.L;
+                        *reinterpret_cast<bf16x4*>(a.vt + ((size_t)f * a.N + n) * a.L + t) = to_bf16x4(acc[i][j] + splat4(b));
+                    }
+                }
+            }
+            return;
+        }
+        f4 bv[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + (wn * TN + i) * 16 + q4;
+            bv[i] = n < a.N ? ld4(bias + n) : splat4(0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + (wn * TN + i) * 16 + q4;
+            if (n >= a.N) continue;                           // N is a multiple of 4; W rows beyond N are zero padding
+            if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
+                // read-modify-write of the f32 residual stream: all TM loads of a column tile are issued before the first
+                // store (a store to `resid` may alias the next load as far as the compiler knows, which would otherwise
+                // serialise TM x TN full memory round trips)
+                f4 old[TM];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    int m = m0 + (wm * TM + j) * 16 + l15;
+                    m = m < a.M ? m : a.M - 1;
+                    if constexpr (EPI == EPI_RESID) old[j] = ld4(a.resid + (size_t)m * a.N + n);
+                    else old[j] = ld4(a.pos + (size_t)(m % a.L) * a.N + n);
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const int m = m0 + (wm * TM + j) * 16 + l15;
+                    if (m < a.M) st4(a.resid + (size_t)m * a.N + n, old[j] + acc[i][j] + bv[i]);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + (wm * TM + j) * 16 + l15;
+                if (m >= a.M) continue;
+                const f4 v = acc[i][j] + bv[i];
+                if constexpr (EPI == EPI_BF16) {
+                    *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(v);
+                } else if constexpr (EPI == EPI_GELU) {
+                    const f4 g = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                    *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(g);
+                } else if constexpr (EPI == EPI_CONV) {
+                    const f4 r = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                    size_t row = (size_t)m;
+                    if (a.out_padded) {
+                        const int FF = a.F * a.F, bb = m / FF, yx = m - bb * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        row = (size_t)((bb * P + y + 1) * P + x + 1);
+                    }
+                    bf16* o = static_cast<bf16*>(a.out) + grp * a.gOut;
+                    int nn = n;
+                    if (a.n_split) { const int t = n / a.n_split; o += (size_t)t * a.gOut; nn = n - t * a.n_split; }
+                    *reinterpret_cast<bf16x4*>(o + row * a.ldo + nn) = to_bf16x4(r);
+                }
+            }
+        }
+    };
 
     const int fr = swz_byte((lane & 15) * 64 + (lane >> 4) * 16);   // fragment byte inside a sub-tile
     const int nk = a.K / BK;
+    // ---- persistent loop over this workgroup's tiles: the DMA of the next tile's first k-tile is issued before the
+    // epilogue of the current one, so its latency hides behind the epilogue's stores
+    int vb = blockIdx.x, m0, n0;
+    if (vb >= nwg) return;
+    tile_of(vb, m0, n0);
+    set_sources(m0, n0);
     stage(0, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        char* cur = smem + (kt & 1) * BUF_BYTES;
-        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF_BYTES);
-        const char* xp = cur + (wm * TM * 2) * 1024 + fr;
-        const char* wp = cur + (SX + wn * TN * 2) * 1024 + fr;
+    for (;;) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fw[TN], fx[TM];
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + (i * 2 + kk) * 1024);
+            for (int j = 0; j < TM; ++j) acc[i][j] = splat4(0.f);
+        for (int kt = 0; kt < nk; ++kt) {
+            char* cur = smem + (kt & 1) * BUF_BYTES;
+            if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF_BYTES);
+            const char* xp = cur + (wm * TM * 2) * 1024 + fr;
+            const char* wp = cur + (SX + wn * TN * 2) * 1024 + fr;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + (j * 2 + kk) * 1024);
-            if constexpr (EPI == EPI_VT) {
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fw[TN], fx[TM];
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + (i * 2 + kk) * 1024);
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[i][j], 0, 0, 0);
-            } else {
+                for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + (j * 2 + kk) * 1024);
+                if constexpr (EPI == EPI_VT) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i)
+                    for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
+        // every wave has passed the barrier that ends the last k-tile: both LDS buffers are free
+        const int cm0 = m0, cn0 = n0;
+        vb += gridDim.x;
+        const bool more = vb < nwg;
+        if (more) {
+            tile_of(vb, m0, n0);
+            set_sources(m0, n0);
+            stage(0, smem);
+        }
+        epilogue(cm0, cn0);
+        if (!more) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-    }
-
-    // ---- epilogue.  Normal tiles: lane holds n = nb + 4q + {0..3} of token m = mb + (lane & 15).
-    const int q4 = (lane >> 4) * 4, l15 = lane & 15;
-    if constexpr (EPI == EPI_VT) {
-        // swapped tile: lane holds tokens m = mb + 4q + {0..3} of feature n = nb + (lane & 15)
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + wn * TN * 16 + i * 16 + l15;
-            const float b = bias[n];
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int m = m0 + (wm * TM + j) * 16 + q4;
-                if (m < a.M) {     // M is a multiple of 4 (L is)
-                    const int f = m / a.L, t = m - f * a.L;
-                    *reinterpret_cast<bf16x4*>(a.vt + ((size_t)f * a.N + n) * a.L + t) = to_bf16x4(acc[i][j] + splat4(b));
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int n = n0 + (wn * TN + i) * 16 + q4;
-        if (n >= a.N) continue;                           // N is a multiple of 4; W rows beyond N are zero padding
-        const f4 b = ld4(bias + n);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + (wm * TM + j) * 16 + l15;
-            if (m >= a.M) continue;
-            const f4 v = acc[i][j] + b;
-            if constexpr (EPI == EPI_PATCH) {
-                const int t = m % a.L;
-                st4(a.resid + (size_t)m * a.N + n, v + ld4(a.pos + (size_t)t * a.N + n));
-            } else if constexpr (EPI == EPI_RESID) {
-                float* p = a.resid + (size_t)m * a.N + n;
-                st4(p, ld4(p) + v);
-            } else if constexpr (EPI == EPI_BF16) {
-                *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(v);
-            } else if constexpr (EPI == EPI_GELU) {
-                const f4 g = {gelu_exact(v.x), gelu_exact(v.y), gelu_exact(v.z), gelu_exact(v.w)};
-                *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(g);
-            } else {   // EPI_CONV
-                const f4 r = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-                size_t row = (size_t)m;
-                if (a.out_padded) {
-                    const int FF = a.F * a.F, bb = m / FF, yx = m - bb * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                    row = (size_t)((bb * P + y + 1) * P + x + 1);
-                }
-                bf16* o = static_cast<bf16*>(a.out) + grp * a.gOut;
-                int nn = n;
-                if (a.n_split) { const int t = n / a.n_split; o += (size_t)t * a.gOut; nn = n - t * a.n_split; }
-                *reinterpret_cast<bf16x4*>(o + row * a.ldo + nn) = to_bf16x4(r);
-            }
-        }
     }
 }
 

@@ -3,6 +3,7 @@
 // vb_attn.h, vb_misc.h.  Reached through the same C ABI as the vit_48 path (vt_create with channels = 768).
 #include "vb_api.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -94,9 +95,20 @@ int upload_bf16(Buf<bf16>& d, const std::vector<float>& h, const Err& E) {
 }
 int upload_f32(Buf<float>& d, const float* h, size_t n, const Err& E) { return upload(d, h, n, E); }
 
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, 0) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    // persistent workgroups: one per CU, each walks tiles blockIdx.x, blockIdx.x + grid, ...
+    const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int tiles = std::min(ntiles, std::max(8, num_cus() / groups / 8 * 8));
     constexpr int lds = vbg::lds_bytes<BM, BN>();
     hipLaunchKernelGGL((vbg::gemm_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(tiles, groups), dim3(512), lds, st, a);
     VB_HIP(hipGetLastError());
