@@ -25,11 +25,15 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(native.LIB_PATH):
         import __graft_entry__ as ge
         ge.build()
-    L = ctypes.CDLL(native.LIB_PATH)
-    for s in _declared_symbols():
-        assert hasattr(L, s), f"{s} declared in include/vittrack.h but not exported"
-    L.vt_version.restype = ctypes.c_char_p
-    assert b"gfx950" in L.vt_version()
+    if not os.path.exists(native.LIB_PATH_F16):
+        import __graft_entry__ as ge
+        ge.build()
+    for path, tag in ((native.LIB_PATH, b"f32"), (native.LIB_PATH_F16, b"f16")):
+        L = ctypes.CDLL(path)
+        for s in _declared_symbols():
+            assert hasattr(L, s), f"{s} declared in include/vittrack.h but not exported by {path}"
+        L.vt_version.restype = ctypes.c_char_p
+        assert b"gfx950" in L.vt_version() and tag in L.vt_version()
 
 
 def test_bad_config_is_rejected_without_gpu():
@@ -44,6 +48,9 @@ def test_bad_config_is_rejected_without_gpu():
     cfg = native.VtConfig(100, 200, 48, 1, 3, 32, 16, 1)
     assert L.vt_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"unsupported geometry" in L.vt_last_error()
+    cfg = native.VtConfig(128, 256, 768, 8, 12, 256, 16, 1)     # ViT-Base with the wrong head count
+    assert L.vt_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"unsupported ViT-Base" in L.vt_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

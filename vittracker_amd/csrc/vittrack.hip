@@ -71,6 +71,9 @@ struct vt_model {
     // workspace sized for max_batch
     DevBuf act_x, act_z;             // layer-2 activations, NHWC(12)
     DevBuf tokens, feat;
+    DevBuf tokens_c;                 // token matrix of the cached-template step: its template rows are written by vt_set_template only
+    DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
+    int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra capture streams for graph chains
@@ -235,8 +238,9 @@ StemPlan stem_plan_default(int T) {
     }
 }
 
-int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0) {
+int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0, int zmode = 0) {
     // f0: first frame of this slice in the model workspace (z, x, tokens already point at the slice)
+    // zmode 0: both crops; 1: search crop only (template token rows already in `tokens`); 2: template crop only
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
     float* const act_z = m->act_z.p + f0 * (size_t)(Tz / 4) * (Tz / 4) * 12;
@@ -253,15 +257,16 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
         hipLaunchKernelGGL(vts::stem_fused_kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p,
                            m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p,
-                           m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps);
+                           m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, zmode);
         HIP_TRY(hipGetLastError());
         return VT_OK;
     }
     const bool pipe = m->stem_pipe && Tx == 256 && Tz == 128;
+    if (zmode != 0 && !pipe) return fail(VT_ERR_STATE, "the template cache needs the default stem kernels (VT_STEM_FUSED / VT_STEM_PIPE = 1)");
     if (pipe) {   // layers 1 + 2 of a frame in one workgroup (two wave groups half a period apart); stem_b follows
         constexpr size_t lds_p = vts::PipeGeo<256, 128>::LDS_BYTES;
         hipLaunchKernelGGL((vts::stem_pipe_kernel<256, 128>), dim3(B), dim3(1024), lds_p, st, z, x,
-                           m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps);
+                           m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps, zmode);
         HIP_TRY(hipGetLastError());
     }
     vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
@@ -281,8 +286,8 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
                            m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
     }
     HIP_TRY(hipGetLastError());
-    vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, (Tx / 16) / px.r4, m->len_z};
-    vts::CropB bz{act_z, m->pos_z.p, Tz / 4, pz.r4, (Tz / 16) / pz.r4, 0};
+    vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, zmode == 2 ? 0 : (Tx / 16) / px.r4, m->len_z};
+    vts::CropB bz{act_z, m->pos_z.p, Tz / 4, pz.r4, zmode == 1 ? 0 : (Tz / 16) / pz.r4, 0};
     const size_t lds_b = std::max(vts::stem_b_lds_bytes(Tx / 4, px.r4), vts::stem_b_lds_bytes(Tz / 4, pz.r4));
     hipLaunchKernelGGL(vts::stem_b_kernel, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
                        m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, m->skip_stem_b);
@@ -300,24 +305,25 @@ size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth) {
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
 template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
-int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid) {
+int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode) {
     const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth);
     hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
-                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps);
+                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
 
-int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid) {
+int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid, int zc = 0) {
+    // zc: template cache mode of block 0 (0 off, 1 store, 2 load)
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     switch (m->L / 16) {
         case 5:
-            if (m->blocks_bal) return launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid);
-            return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid)
-                                  : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid);
+            if (m->blocks_bal) return launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
+            return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                                  : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
-            return m->blocks_bal ? launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid)
-                                 : launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid);
+            return m->blocks_bal ? launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid, zc)
+                                 : launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
     }
 }
@@ -446,7 +452,7 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
 extern "C" {
 
 const char* vt_last_error(void) { return g_err.c_str(); }
-const char* vt_version(void) { return "vittrack-hip 0.1 (gfx950)"; }
+const char* vt_version(void) { return "vittrack-hip 0.2 (gfx950, " VT_PRECISION_NAME " contractions)"; }
 
 int vt_create(const vt_config* cfg, vt_model** out) {
     if (!cfg || !out) return fail(VT_ERR_ARG, "null argument");
@@ -483,12 +489,15 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
     A(m->tokens, B * m->L * 48);
     A(m->feat, B * m->len_x * 48);
+    A(m->tokens_c, B * m->L * 48);
+    A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
     A(m->score, B * m->len_x);
     A(m->size, B * 2 * m->len_x);
     A(m->offset, B * 2 * m->len_x);
     A(m->pred, B * 4);
     A(m->hann, B * 4);
     A(m->conf, B);
+    if (!rc && hipMemset(m->tokens_c.p, 0, m->tokens_c.n * sizeof(float)) != hipSuccess) rc = fail(VT_ERR_HIP, "hipMemset(tokens) failed");
     m->skip_stem_a = env_int("VT_SKIP_STEM_A", 0);
     m->skip_stem_b = env_int("VT_SKIP_STEM_B", 0);
     m->skip_head = env_int("VT_SKIP_HEAD", 0);
@@ -562,7 +571,7 @@ void vt_destroy(vt_model* m) {
     if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->act_x.release(); m->act_z.release();
-    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat,
+    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
@@ -719,8 +728,16 @@ int vt_head(vt_model* m, const float* feat_dev, int32_t B, void* stream, const v
 int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, void* stream, const vt_outputs* out) {
     int rc = check_ready(m, B);
     if (rc) return rc;
-    if (!z_dev || !x_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (!x_dev) return fail(VT_ERR_ARG, "null device pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!z_dev) {   // cached template (vt_set_template): stem on the search crop only, block 0 loads the template's q / k / v
+        if (m->vb) return fail(VT_ERR_ARG, "the template cache is implemented for the vit_48 path only");
+        if (m->tmpl_frames < B)
+            return fail(VT_ERR_STATE, "vt_forward with a null template needs vt_set_template for at least " + std::to_string(B) + " frames first");
+        if ((rc = run_stem(m, nullptr, x_dev, B, st, m->tokens_c.p, 0, 1))) return rc;
+        if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
+        return run_head(m, m->feat.p, B, st, out);
+    }
     if (m->vb) {
         std::string err;
         if ((rc = vb::stem(m->vb, z_dev, x_dev, B, st, nullptr, &err))) return fail(rc, err);
@@ -730,6 +747,22 @@ int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, v
     if ((rc = run_stem(m, z_dev, x_dev, B, st, m->tokens.p))) return rc;
     if ((rc = run_blocks(m, m->tokens.p, B, -1, st, m->feat.p, nullptr))) return rc;
     return run_head(m, m->feat.p, B, st, out);
+}
+
+int vt_set_template(vt_model* m, const float* z_dev, int32_t B, void* stream) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!z_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb) return fail(VT_ERR_ARG, "the template cache is implemented for the vit_48 path only");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    m->tmpl_frames = 0;
+    // template token rows (stem(z) + pos_embed_z) stay in the cached step's own token matrix (uncached steps use another) ...
+    if ((rc = run_stem(m, z_dev, nullptr, B, st, m->tokens_c.p, 0, 2))) return rc;
+    // ... and block 0's LN1 + qkv of those rows goes to the cache.  One block over the whole token matrix: the search
+    // rows hold whatever the last cached frame left (per-token work, nothing of theirs is stored); the outputs are scratch.
+    if ((rc = run_blocks(m, m->tokens_c.p, B, 1, st, m->feat.p, nullptr, 1))) return rc;
+    m->tmpl_frames = B;
+    return VT_OK;
 }
 
 int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, const float* offset_dev, int32_t B,
@@ -783,7 +816,7 @@ int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_
     // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
     // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
     int nch = m->graph_chains;   // default 1
-    nch = m->vb ? 1 : std::max(1, std::min({nch, 4, (int)B}));
+    nch = (m->vb || !z_dev) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }

@@ -198,7 +198,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                                                          float* __restrict__ resid,          // (B, L, C) or null
                                                          int len_z, int depth_total, int nblocks,
                                                          int dbg_skip_tile,                  // timing experiments only (-1)
-                                                         unsigned long long* __restrict__ stamps) {   // diagnostic, null in production
+                                                         unsigned long long* __restrict__ stamps,   // diagnostic, null in production
+                                                         // exact template cache (BASELINE config 5): block 0's LN1 + qkv of the template rows is
+                                                         // frame-invariant (the template tokens are; LN and the projections act per token).
+                                                         // [B][len_z/16][9][64] f4: q, k, v^T images of each template tile.
+                                                         float* __restrict__ zcache,
+                                                         int zcache_mode) {   // 0: off, 1: compute and store, 2: load instead of computing
     static_assert(NW * TPW >= NT, "tiles must be covered");
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
     constexpr int L = NT * 16;
@@ -281,7 +286,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NOWN && T != dbg_skip_tile) {
+            const bool z_tile = blk == 0 && 16 * T < len_z;       // wave-uniform
+            f4* const zc = reinterpret_cast<f4*>(zcache) + (((size_t)b * (len_z >> 4) + T) * 3 * NC) * 64 + lane;
+            if (T < NOWN && T != dbg_skip_tile && z_tile && zcache_mode == 2) {
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) {
+                    qr[i][ot] = zc[ot * 64];
+                    Kimg[(T * NC + ot) * 64 + lane] = zc[(NC + ot) * 64];
+                    Vimg[(ot * NT + T) * 64 + lane] = zc[(2 * NC + ot) * 64];
+                }
+            } else if (T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
                 layer_norm_img(x[i], h, S + S_LN1G, S + S_LN1B, q);
                 fstamp();
@@ -299,6 +313,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     for (int ot = 0; ot < NC; ++ot) {
                         qr[i][ot] = acc[ot];
                         Kimg[(T * NC + ot) * 64 + lane] = acc[NC + ot];
+                        if (z_tile && zcache_mode == 1) { zc[ot * 64] = acc[ot]; zc[(NC + ot) * 64] = acc[NC + ot]; }
                     }
                 }
                 fstamp();
@@ -313,7 +328,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         },
                         [&](int c) { return h[c]; }, acc);
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
+                    for (int ot = 0; ot < NC; ++ot) {
+                        Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
+                        if (z_tile && zcache_mode == 1) zc[(2 * NC + ot) * 64] = acc[ot];
+                    }
                 }
             }
         }

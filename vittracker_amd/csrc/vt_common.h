@@ -7,12 +7,41 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define VT_WAVE 64
 
-// Four chained v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains, 16 k-values per call).
+// One 16-deep k-chunk of a 16x16 tile: D += A(16 x 16) B(16 x 16) on operand images.
+//
 // Operand convention used everywhere ("operand image"): a lane's f4 holds, for its row/column
 // index (lane & 15) and quarter q = lane >> 4, the four k-values 4q + r (r = 0..3) of a 16-wide
-// k chunk.  MFMA step r consumes element r of both operands, so step r's hardware k-slot
-// (lane >> 4) stands for k = 4q + r on BOTH sides: the k order is permuted identically for A and
-// B, which leaves the product unchanged.  Result: D[row = 4q + r][col = lane & 15] in element r.
+// k chunk.  Result: D[row = 4q + r][col = lane & 15] in element r.
+//
+// fp32 build (default): four chained v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains).  MFMA step r
+// consumes element r of both operands, so step r's hardware k-slot (lane >> 4) stands for k = 4q + r
+// on BOTH sides: the k order is permuted identically for A and B, which leaves the product unchanged.
+//
+// VT_F16 build (libvittrack_hip_f16.so, BASELINE config 5): the SAME operand image is exactly the
+// operand layout of v_mfma_f32_16x16x16_f16 (lane holds A[row = lane & 15][k = 4 (lane >> 4) + j]),
+// so each chunk is ONE MFMA on the operands rounded to f16 (RNE), accumulating in f32.  Every
+// contraction of every kernel goes through the helpers below, so the whole step switches precision
+// with the build flag; LayerNorm, softmax, GELU, Hardswish, sigmoid and the residual stream stay f32.
+#ifdef VT_F16
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h4 to_h4(f4 v) { return __builtin_convertvector(v, h4); }
+__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(a), to_h4(b), acc, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void mfma4_shared_b(const f4 (&a)[N], f4 b, f4 (&acc)[N]) {
+    const h4 hb = to_h4(b);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(to_h4(a[n]), hb, acc[n], 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)[N]) {
+    const h4 ha = to_h4(a);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, to_h4(b[n]), acc[n], 0, 0, 0);
+}
+#define VT_PRECISION_NAME "f16"
+#else
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
@@ -39,6 +68,8 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
 #pragma unroll
         for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[n][r], acc[n], 0, 0, 0);
 }
+#define VT_PRECISION_NAME "f32"
+#endif
 
 __device__ __forceinline__ f4 splat4(float v) { return f4{v, v, v, v}; }
 

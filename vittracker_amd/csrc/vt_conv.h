@@ -67,6 +67,12 @@ __device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT
             // their first use and every chunk then starts with a full LDS round trip
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef VT_F16
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) acc[i][ot] = mfma4(a[k][ot], b[k & 1][i], acc[i][ot]);
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -74,6 +80,7 @@ __device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT
 #pragma unroll
                 for (int i = 0; i < NPT; ++i)
                     acc[i][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][ot][r], b[k & 1][i][r], acc[i][ot], 0, 0, 0);
+#endif
     }
 }
 

@@ -65,8 +65,10 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
     const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
     const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip,
-    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    int zmode) {   // 0: both crops; 1: search crop only (the template's token rows are cached in `tokens`); 2: template only
     using G = FusedGeo;
+    const bool do_z = zmode != 1, do_x = zmode != 2;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     f4* const lds = reinterpret_cast<f4*>(lds_f);
     f4* const ring0 = lds;                                   // group A's layer-1 ring
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     stamp();
     // ---- start: the first bands' inputs are requested before the LDS is cleared ---------------------------
     f4 v[3][3];
-    fetch(band(0), v);
+    if (grp == 0 ? do_z : do_x) fetch(band(0), v);
     {   // constants -> LDS; zero only what is read without ever being written: the top rows of the rings,
         // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
         const int t = threadIdx.x;
@@ -246,23 +248,24 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     if (skip & 1) load_w3();
     if (!(skip & 1)) {
         const bool l2 = !(skip & 2);
+        // zmode: a crop that is not wanted keeps its barriers and drops its work (all conditions are wave-uniform)
         if (grp == 0) {
-            layer1(band(0), v);                     stamp(); __syncthreads(); stamp();   // 0: L1(z)
-            fetch(band(1), v);
-            if (l2) layer2(band(0));                stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
-            layer1(band(1), v);                     stamp(); __syncthreads(); stamp();   // 2: L1(x1)
-            fetch(band(2), v);
-            if (l2) layer2(band(1));                stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
-            layer1(band(2), v);                     stamp(); __syncthreads(); stamp();   // 4: L1(x3)
+            if (do_z) layer1(band(0), v);           stamp(); __syncthreads(); stamp();   // 0: L1(z)
+            if (do_x) fetch(band(1), v);
+            if (l2 && do_z) layer2(band(0));        stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
+            if (do_x) layer1(band(1), v);           stamp(); __syncthreads(); stamp();   // 2: L1(x1)
+            if (do_x) fetch(band(2), v);
+            if (l2 && do_x) layer2(band(1));        stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
+            if (do_x) layer1(band(2), v);           stamp(); __syncthreads(); stamp();   // 4: L1(x3)
             load_w3();
-            if (l2) layer2(band(2));                stamp(); __syncthreads(); stamp();   // 5: L2(x3)
+            if (l2 && do_x) layer2(band(2));        stamp(); __syncthreads(); stamp();   // 5: L2(x3)
         } else {
             stamp(); __syncthreads(); stamp();   // 0: (x0 requested at kernel start)
-            layer1(band(0), v);                     stamp(); __syncthreads(); stamp();   // 1: L1(x0)
-            fetch(band(1), v);
-            if (l2) layer2(band(0));                stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
-            layer1(band(1), v);                     stamp(); __syncthreads(); stamp();   // 3: L1(x2)
-            if (l2) layer2(band(1));                stamp(); __syncthreads(); stamp();   // 4: L2(x2)
+            if (do_x) layer1(band(0), v);           stamp(); __syncthreads(); stamp();   // 1: L1(x0)
+            if (do_x) fetch(band(1), v);
+            if (l2 && do_x) layer2(band(0));        stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
+            if (do_x) layer1(band(1), v);           stamp(); __syncthreads(); stamp();   // 3: L1(x2)
+            if (l2 && do_x) layer2(band(1));        stamp(); __syncthreads(); stamp();   // 4: L2(x2)
             load_w3();                              __syncthreads();   // 5
         }
     }
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         }
         const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
         if (!(skip & 4)) {
-            {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
+            if (do_x) {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
                 constexpr int P2 = G::TX / 4 + 1, H2 = G::TX / 8, P3 = G::TX / 8 + 1, H3 = G::TX / 16;
                 int base[2];
 #pragma unroll
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                     }
                 }
             }
-            if (wave < 8) {   // template: 4 pixel tiles of the 8 x 8 map
+            if (wave < 8 && do_z) {   // template: 4 pixel tiles of the 8 x 8 map
                 constexpr int P2 = G::TZ / 4 + 1, H2 = G::TZ / 8, P3 = G::TZ / 8 + 1, H3 = G::TZ / 16;
                 const int op = 16 * (wave >> 1) + px, y = op >> 3, x = op & 7;
                 int base[1] = {2 * y * P2 + x};
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     stamp();
 
     // ---- layer 4 (24 -> 48) + pos-embed -> token rows: 15 (pixel tile, output tile) items, one per wave ------
-    if (wave < 15 && !(skip & 8)) {
+    if (wave < 15 && !(skip & 8) && (z4 ? do_z : do_x)) {
         const bool is_z = z4;
         const int tile = tile4, ot = ot4;
         const int lgS4 = is_z ? 2 : 3;
@@ -366,8 +369,10 @@ template <int TX, int TZ>
 __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip,
-    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    int zmode) {   // 0: both crops; 1: search bands only (template cached downstream); 2: template bands only
     using G = PipeGeo<TX, TZ>;
+    const int s_lo = zmode == 1 ? G::NBZ / 2 : 0, s_hi = zmode == 2 ? G::NBZ / 2 : G::NB / 2;   // band pairs [s_lo, s_hi)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     f4* const ring0 = reinterpret_cast<f4*>(lds_f);
     f4* const cw2 = ring0 + 2 * G::RING;
@@ -492,18 +497,18 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     };
     stamp();
     f4 v[3][3];
-    fetch(band(grp), v);
+    fetch(band(2 * s_lo + grp), v);
     if (threadIdx.x < 5 * 64) cw2[threadIdx.x] = ld4(w2img + 4 * threadIdx.x);
     else if (threadIdx.x < 5 * 64 + 4) cw2[threadIdx.x] = ld4(b2 + 4 * (threadIdx.x - 320));
     // group B works one interval behind group A; both execute NB + 1 barriers
     if (grp == 1) __syncthreads();
-    for (int s = 0; s < G::NB / 2; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const int j = 2 * s + grp;
         if (!(skip & 1)) layer1(band(j), v);
         stamp();
         __syncthreads();
         stamp();
-        fetch(band(j + 2 < G::NB ? j + 2 : j), v);              // the next band of this group, a whole interval ahead
+        fetch(band(j + 2 < 2 * s_hi ? j + 2 : j), v);          // the next band of this group, a whole interval ahead
         if (!(skip & 2)) layer2(band(j));
         stamp();
         __syncthreads();

@@ -14,12 +14,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvittrack_hip.so")
+#: the same sources built with every vit_48 contraction on f16 MFMA (BASELINE config 5; make -C csrc all)
+LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvittrack_hip_f16.so")
+PRECISIONS = ("f32", "f16")
 
 #: every symbol include/vittrack.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
+    "vt_set_template",
 ]
 
 
@@ -40,22 +44,28 @@ class VtOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")]
 
 
-_lib = None
+_lib = None          # the fp32 library (kept as a module attribute: __graft_entry__.build() resets it)
+_libs = {}
 
 
-def lib():
-    """Load the library once.  Raises VtError (never falls back) when it has not been built."""
+def lib(precision: str = "f32"):
+    """Load a library once.  Raises VtError (never falls back) when it has not been built."""
     global _lib
-    if _lib is not None:
+    if precision not in PRECISIONS:
+        raise VtError(f"unknown precision {precision!r}: 'f32' (default) or 'f16'")
+    if precision == "f32" and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise VtError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                      f"or `make -C vittracker_amd/csrc` (there is no CPU fallback)")
+    if precision != "f32" and precision in _libs:
+        return _libs[precision]
+    path = LIB_PATH if precision == "f32" else LIB_PATH_F16
+    if not os.path.exists(path):
+        raise VtError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C vittracker_amd/csrc all` (there is no CPU fallback)")
     # PyTorch-ROCm ships its own copy of the HIP runtime.  It has to be loaded before this library pulls in the
     # system libamdhip64: in the opposite order torch.cuda.is_available() turns False for the rest of the process
     # (seen when a process created a Model before it had ever imported torch).
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int32
     L.vt_last_error.restype = C.c_char_p
     L.vt_version.restype = C.c_char_p
@@ -79,13 +89,17 @@ def lib():
     L.vt_debug_stamps.argtypes = [vp, i32, vp]
     L.vt_crop.argtypes = [vp, vp, i32, i32, vp, C.c_double, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp]
     L.vt_update_state.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
-    _lib = L
+    L.vt_set_template.argtypes = [vp, vp, i32, vp]
+    if precision == "f32":
+        _lib = L
+    else:
+        _libs[precision] = L
     return L
 
 
-def _check(rc: int, what: str):
+def _check(rc: int, what: str, L=None):
     if rc != 0:
-        raise VtError(f"{what} failed ({rc}): {lib().vt_last_error().decode()}")
+        raise VtError(f"{what} failed ({rc}): {(L or lib()).vt_last_error().decode()}")
 
 
 def _ptr(t):
@@ -141,21 +155,22 @@ class Graph:
         self._h = handle
         self._keep = keep   # tensors the captured kernels read / write
         self._model = model
+        self._L = model._L if model is not None else lib()
         self._valid = True
 
     def launch(self, stream=None):
         if not self._valid:
             raise VtError("this graph was captured from a model that has since been closed or re-sized "
                           "(its weight / workspace buffers are gone): capture it again")
-        _check(lib().vt_graph_launch(self._h, _stream(stream)), "vt_graph_launch")
+        _check(self._L.vt_graph_launch(self._h, _stream(stream)), "vt_graph_launch", self._L)
 
     def _invalidate(self):
         self._valid = False
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and getattr(self, "_L", None) is not None:
             try:
-                _lib.vt_graph_destroy(self._h)
+                self._L.vt_graph_destroy(self._h)
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
             self._h = None
@@ -165,13 +180,17 @@ class Model:
     """Owns one ``vt_model`` (weights + workspace on the current device)."""
 
     def __init__(self, template_size, search_size, channels=48, heads=1, depth=3, head_channels=32, stride=16,
-                 max_batch=1):
+                 max_batch=1, precision="f32"):
+        """precision: 'f32' (exact fp32 contractions, the parity path) or 'f16' (vit_48 contractions on f16 MFMA,
+        BASELINE config 5).  The ViT-Base path (channels=768) always contracts in bf16."""
+        self.precision = precision
+        self._L = lib(precision)
         self.cfg = VtConfig(template_size, search_size, channels, heads, depth, head_channels, stride, max_batch)
         h = C.c_void_p()
-        _check(lib().vt_create(C.byref(self.cfg), C.byref(h)), "vt_create")
+        _check(self._L.vt_create(C.byref(self.cfg), C.byref(h)), "vt_create", self._L)
         self._h = h
         q = [C.c_int32() for _ in range(4)]
-        _check(lib().vt_query(self._h, *[C.byref(v) for v in q]), "vt_query")
+        _check(self._L.vt_query(self._h, *[C.byref(v) for v in q]), "vt_query", self._L)
         self.len_z, self.len_x, self.feat_sz, self.channels = [v.value for v in q]
         self.L = self.len_z + self.len_x
         self.max_batch = max_batch
@@ -206,9 +225,9 @@ class Model:
     def close(self):
         for g in list(getattr(self, "_graphs", ())):
             g._invalidate()
-        if getattr(self, "_h", None) and _lib is not None:
+        if getattr(self, "_h", None) and getattr(self, "_L", None) is not None:
             try:
-                _lib.vt_destroy(self._h)
+                self._L.vt_destroy(self._h)
             except Exception:  # noqa: BLE001  (interpreter shutdown)
                 pass
             self._h = None
@@ -230,30 +249,49 @@ class Model:
             keep.append(a)
             arr[n] = VtTensor(k.encode(), a.ctypes.data, a.size)
             n += 1
-        _check(lib().vt_load_weights(self._h, arr, n), "vt_load_weights")
+        _check(self._L.vt_load_weights(self._h, arr, n), "vt_load_weights", self._L)
 
     def set_window(self, win):
         a = np.ascontiguousarray(np.asarray(win, dtype=np.float32).reshape(-1))
         if a.size != self.feat_sz ** 2:
             raise VtError(f"window must have {self.feat_sz ** 2} elements")
-        _check(lib().vt_set_window(self._h, a.ctypes.data), "vt_set_window")
+        _check(self._L.vt_set_window(self._h, a.ctypes.data), "vt_set_window", self._L)
 
     # ---- whole step
+    def set_template(self, z, stream=None):
+        """Exact template cache (vt_set_template): afterwards ``forward(None, x)`` / ``capture(None, x)`` skip the
+        template's patch embedding and block 0's LayerNorm-1 + qkv of its rows."""
+        B, tz = z.shape[0], self.template_size
+        if tuple(z.shape) != (B, 3, tz, tz):
+            raise VtError(f"expected z (B,3,{tz},{tz}), got {tuple(z.shape)}")
+        self._check_batch(B)
+        _check(self._L.vt_set_template(self._h, _ptr(z), B, _stream(stream)), "vt_set_template", self._L)
+        self._tmpl_B = B
+
+    def _check_x_only(self, x):
+        B, tx = x.shape[0], self.search_size
+        if tuple(x.shape) != (B, 3, tx, tx):
+            raise VtError(f"expected x (B,3,{tx},{tx}), got {tuple(x.shape)}")
+        self._check_batch(B)
+        if getattr(self, "_tmpl_B", 0) < B:
+            raise VtError(f"forward with z=None needs set_template() for at least {B} frames first")
+        return B
+
     def forward(self, z, x, out: Outputs | None = None, stream=None) -> Outputs:
-        B = self._check_crops(z, x)
-        out = out or Outputs(B, self.feat_sz, z.device)
+        B = self._check_crops(z, x) if z is not None else self._check_x_only(x)
+        out = out or Outputs(B, self.feat_sz, x.device)
         self._check_out(out, B)
         st = out.struct()
-        _check(lib().vt_forward(self._h, _ptr(z), _ptr(x), B, _stream(stream), C.byref(st)), "vt_forward")
+        _check(self._L.vt_forward(self._h, _ptr(z), _ptr(x), B, _stream(stream), C.byref(st)), "vt_forward", self._L)
         return out
 
     def capture(self, z, x, out: Outputs | None = None) -> tuple[Graph, Outputs]:
-        B = self._check_crops(z, x)
-        out = out or Outputs(B, self.feat_sz, z.device)
+        B = self._check_crops(z, x) if z is not None else self._check_x_only(x)
+        out = out or Outputs(B, self.feat_sz, x.device)
         self._check_out(out, B)
         st = out.struct()
         g = C.c_void_p()
-        _check(lib().vt_graph_capture(self._h, _ptr(z), _ptr(x), B, C.byref(st), C.byref(g)), "vt_graph_capture")
+        _check(self._L.vt_graph_capture(self._h, _ptr(z), _ptr(x), B, C.byref(st), C.byref(g)), "vt_graph_capture", self._L)
         gr = Graph(g, (z, x, out), self)
         self._graphs.add(gr)
         return gr, out
@@ -263,7 +301,7 @@ class Model:
         import torch
         B = self._check_crops(z, x)
         tok = torch.empty(B, self.L, self.channels, device=z.device)
-        _check(lib().vt_stem(self._h, _ptr(z), _ptr(x), B, _stream(stream), _ptr(tok)), "vt_stem")
+        _check(self._L.vt_stem(self._h, _ptr(z), _ptr(x), B, _stream(stream), _ptr(tok)), "vt_stem", self._L)
         return tok
 
     def blocks(self, tokens, nblocks=-1, want_resid=False, stream=None, feat=None):
@@ -277,7 +315,7 @@ class Model:
         elif tuple(feat.shape) != (B, self.len_x, self.channels):
             raise VtError(f"feat must be (B,{self.len_x},{self.channels}), got {tuple(feat.shape)}")
         resid = torch.empty_like(tokens) if want_resid else None
-        _check(lib().vt_blocks(self._h, _ptr(tokens), B, nblocks, _stream(stream), _ptr(feat), _ptr(resid)), "vt_blocks")
+        _check(self._L.vt_blocks(self._h, _ptr(tokens), B, nblocks, _stream(stream), _ptr(feat), _ptr(resid)), "vt_blocks", self._L)
         return (feat, resid) if want_resid else feat
 
     def head(self, feat, out: Outputs | None = None, stream=None) -> Outputs:
@@ -288,7 +326,7 @@ class Model:
         out = out or Outputs(B, self.feat_sz, feat.device)
         self._check_out(out, B)
         st = out.struct()
-        _check(lib().vt_head(self._h, _ptr(feat), B, _stream(stream), C.byref(st)), "vt_head")
+        _check(self._L.vt_head(self._h, _ptr(feat), B, _stream(stream), C.byref(st)), "vt_head", self._L)
         return out
 
     # ---- pre / post steps of track() on the device
@@ -313,9 +351,9 @@ class Model:
             raise VtError(f"resize_factor must be a ({B},) float64 tensor on the GPU")
         m3 = (C.c_float * 3)(*[float(v) for v in mean])
         s3 = (C.c_float * 3)(*[float(v) for v in std])
-        _check(lib().vt_crop(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor),
+        _check(self._L.vt_crop(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor),
                              out_size, m3, s3, B, _stream(stream), _ptr(out), C.c_void_p(resize_factor.data_ptr())),
-               "vt_crop")
+               "vt_crop", self._L)
         return out, resize_factor
 
     def update_state(self, hann_boxes, resize_factor, states, search_size, H, W, margin=10, stream=None):
@@ -324,8 +362,8 @@ class Model:
                 or states.dtype != resize_factor.dtype or not states.is_cuda or not resize_factor.is_cuda):
             raise VtError(f"update_state wants hann_boxes ({B},4) fp32, resize_factor ({B},) fp64 and states ({B},4) fp64 "
                           f"on the GPU")
-        _check(lib().vt_update_state(self._h, _ptr(hann_boxes), C.c_void_p(resize_factor.data_ptr()), search_size, H, W,
-                                     margin, B, _stream(stream), C.c_void_p(states.data_ptr())), "vt_update_state")
+        _check(self._L.vt_update_state(self._h, _ptr(hann_boxes), C.c_void_p(resize_factor.data_ptr()), search_size, H, W,
+                                     margin, B, _stream(stream), C.c_void_p(states.data_ptr())), "vt_update_state", self._L)
         return states
 
     def cal_bbox(self, score, size, offset, stream=None):
@@ -336,6 +374,6 @@ class Model:
                           f"{tuple(size.shape)}, {tuple(offset.shape)}")
         bbox = torch.empty(B, 4, device=score.device)
         mx = torch.empty(B, device=score.device)
-        _check(lib().vt_cal_bbox(self._h, _ptr(score), _ptr(size), _ptr(offset), B, _stream(stream), _ptr(bbox), _ptr(mx)),
-               "vt_cal_bbox")
+        _check(self._L.vt_cal_bbox(self._h, _ptr(score), _ptr(size), _ptr(offset), B, _stream(stream), _ptr(bbox), _ptr(mx)),
+               "vt_cal_bbox", self._L)
         return bbox, mx
