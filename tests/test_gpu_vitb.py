@@ -103,6 +103,36 @@ def test_vitb_batch_invariance_and_odd_batches():
             assert torch.equal(getattr(one, k)[0], getattr(full, k)[i]), (i, k)
 
 
+def test_vitb_persistent_workgroups_large_batch():
+    """At batch 96 every GEMM has more tiles than the chip has CUs: each workgroup walks several tiles (next tile's
+    operands prefetched behind the epilogue, bias carried a tile ahead).  Frames of the big batch must equal the same
+    frames computed four at a time, bit for bit."""
+    import torch
+    from vittracker_amd import synth
+    sd = synth.synth_vitb_state_dict(26)
+    B = 96
+    z, x = synth.synth_inputs(7, B, 128, 256)
+    m = _model(sd, B)
+    zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+    full = m.forward(zd, xd)
+    assert torch.isfinite(full.score_map).all()
+    for i0 in (0, 44, 92):
+        part = m.forward(zd[i0:i0 + 4].contiguous(), xd[i0:i0 + 4].contiguous())
+        for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes"):
+            assert torch.equal(getattr(part, k), getattr(full, k)[i0:i0 + 4]), (i0, k)
+
+
+def test_decode_of_a_nan_map_stays_in_bounds():
+    import torch
+    from vittracker_amd import native, synth
+    m = native.Model(64, 128, max_batch=2)
+    m.load_state_dict(synth.synth_state_dict(0, len_z=16, len_x=64))
+    score = torch.full((2, 1, 8, 8), float("nan"), device="cuda")
+    bbox, mx = m.cal_bbox(score, torch.rand(2, 2, 8, 8, device="cuda"), torch.rand(2, 2, 8, 8, device="cuda"))
+    torch.cuda.synchronize()
+    assert bbox.shape == (2, 4)
+
+
 def test_vitb_rejects_unsupported_configurations():
     from vittracker_amd import native
     with pytest.raises(native.VtError, match="unsupported ViT-Base"):
@@ -110,3 +140,25 @@ def test_vitb_rejects_unsupported_configurations():
     with pytest.raises(native.VtError, match="missing key"):
         m = native.Model(128, 256, channels=768, heads=12, depth=2, head_channels=256)
         m.load_state_dict({"backbone.norm.weight": np.zeros(768, np.float32)})
+
+
+def test_build_ostrack_model_level_surface():
+    """build_ostrack(cfg) -> load_state_dict(strict=False) -> cuda().eval() -> forward(template=, search=) like
+    lib/models/ostrack/ostrack.py, on the reference fixture."""
+    import torch
+    from conftest import REPO
+    from vittracker_amd import config
+    from vittracker_amd.model_vitb import build_ostrack
+    g, sd, z, x = load_vitb_case(vitb_golden_files()[0])
+    c = config.fresh_cfg()
+    config.update_config_from_file(os.path.join(REPO, "experiments/ostrack/vitb_256.yaml"), c)
+    net = build_ostrack(c, training=False, max_batch=int(g["B"]))
+    r = net.load_state_dict({**{k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, "some.training_only.key": torch.zeros(1)}, strict=False)
+    assert r.unexpected_keys == ["some.training_only.key"] and not r.missing_keys
+    net = net.cuda().eval()
+    out = net(template=torch.from_numpy(z).cuda(), search=torch.from_numpy(x).cuda())
+    assert out["pred_boxes"].shape == (int(g["B"]), 1, 4) and net.box_head.feat_sz == 16
+    np.testing.assert_allclose(out["score_map"].cpu().numpy(), g["score_map"], atol=TOL_MAP["score_map"], rtol=0)
+    np.testing.assert_allclose(out["pred_boxes"].cpu().numpy()[:, 0], g["pred_boxes"][:, 0], atol=TOL_BOX, rtol=0)
+    with pytest.raises(NotImplementedError):
+        net(template=torch.from_numpy(z).cuda(), search=torch.from_numpy(x).cuda(), ce_template_mask=torch.zeros(1))

@@ -238,3 +238,17 @@ def test_bench_refuses_diagnostic_switches():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--plumbing-only", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "refuses to run" in (r.stdout + r.stderr)
+
+
+def test_build_ostrack_config_surface():
+    from vittracker_amd import config
+    from vittracker_amd.model_vitb import build_ostrack
+    c = config.fresh_cfg()
+    config.update_config_from_file(os.path.join(REPO, "experiments/ostrack/vitb_256.yaml"), c)
+    net = build_ostrack(c, training=False)
+    sd = net.state_dict()
+    assert sd["backbone.blocks.11.mlp.fc2.weight"].shape == (768, 3072) and sd["box_head.conv1_ctr.0.weight"].shape == (256, 768, 3, 3)
+    assert sd["backbone.pos_embed_z"].shape == (1, 64, 768) and net.box_head.feat_sz == 16
+    c.MODEL.BACKBONE.TYPE = "vit_base_patch16_224_ce"
+    with pytest.raises(NotImplementedError):
+        build_ostrack(c, training=False)

@@ -12,8 +12,15 @@
 // Operand panels go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into 16-row x 32-k
 // sub-tiles of 1 KiB whose two 8-row halves are XOR-ed by 32 bytes ("st_16x32": ds_read_b128 of a fragment is then
 // conflict-free); the swizzle is applied to the per-lane SOURCE address and to the fragment read, the LDS destination
-// of a DMA stays lane-linear.  Two LDS buffers: the DMA of k-tile t+1 is issued before the MFMAs of tile t, one
-// vmcnt(0) + barrier per k-tile.
+// of a DMA stays lane-linear.
+//
+// Pipeline (256 x 256 tile): FOUR LDS stages of one 32-deep k-step each (4 x 32 KiB); the DMAs of k-steps t+1 .. t+3 are
+// in flight while step t is multiplied -- 96 KiB per CU, which is what it takes to cover the HBM / Infinity-Cache
+// latency of a streamed left operand (measured: with one 64-deep k-tile in flight the fc2 GEMM, whose 503 MB operand
+// comes from HBM, ran at 2.9 us per k-tile against 1.7 us for the L2-resident conv1 operand).  Per step: a COUNTED
+// s_waitcnt vmcnt(8) (the two younger steps stay in flight; never 0 inside a tile), one raw s_barrier, the DMA of step
+// t+3 into the stage step t-1 just vacated, 12 ds_read_b128 and 32 MFMAs per wave.  The narrow tile (256 x 64, head
+// convs 2-4) keeps the simple two-buffer 64-deep loop.
 //
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so id -> (id % 8) * per_xcd +
 // id / 8 gives every XCD a contiguous run of tiles, n fastest: the X panel of a tile row is fetched into that XCD's L2
@@ -21,6 +28,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "vt_common.h"
 
@@ -62,7 +71,18 @@ struct Args {
     long long gX, gW, gOut;
     int gBias;
     int n_split;          // EPI_CONV with towers concatenated along N: columns per tower (0 = none); tower t writes out + t * gOut
+    int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
+                          // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
+                          // 4 = no MFMAs, 8 = no epilogue
 };
+
+// The epilogue staging area is written and read back through differently typed pointers by the same wave: the accesses
+// are declared may_alias and fenced, so neither type-based alias analysis nor the scheduler can move a read above the
+// write that feeds it (DS operations of one wave execute in order; the waits are the compiler's).
+typedef bf16x4 __attribute__((may_alias)) bf16x4a;
+typedef uint4 __attribute__((may_alias)) uint4a;
+typedef f4 __attribute__((may_alias)) f4a;
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ int swz_byte(int p) { return p ^ (((p >> 9) & 1) << 5); }   // st_16x32, involution on [0, 1024)
 
@@ -85,6 +105,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     static_assert((SX + SW) % NWAVES == 0 && SX % NWAVES == 0, "panel split");
     constexpr int NSX = SX / NWAVES;
     constexpr int BUF_BYTES = (SX + SW) * 1024;
+    constexpr bool PIPE4 = (BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0;     // 4-stage pipeline (256 x 256)
+    constexpr int EP_OFF = 2 * BUF_BYTES;                                           // epilogue staging: 8 waves x 4 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -145,142 +167,274 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
 
     f4 acc[TN][TM];
     const int q4 = (lane >> 4) * 4, l15 = lane & 15;
-    // Normal tiles: lane holds n = nb + 4q + {0..3} of token m = mb + (lane & 15).
-    auto epilogue = [&](int m0, int n0) {
-        if constexpr (EPI == EPI_VT) {
-            // swapped tile: lane holds tokens m = mb + 4q + {0..3} of feature n = nb + (lane & 15)
-#pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int n = n0 + wn * TN * 16 + i * 16 + l15;
-                const float b = bias[n];
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int m = m0 + (wm * TM + j) * 16 + q4;
-                    if (m < a.M) {     // M is a multiple of 4 (L is)
-                        const int f = m / a.L, t = m - f * a.L;
-                        *reinterpret_cast<bf16x4*>(a.vt + ((size_t)f * a.N + n) * a.L + t) = to_bf16x4(acc[i][j] + splat4(b));
-                    }
-                }
-            }
-            return;
-        }
-        f4 bv[TN];
+    // Bias: the accumulators START at the bias (loaded a tile ahead, so no load of the epilogue ever waits while the next
+    // tile's DMA is in flight -- hipcc answers such a wait with vmcnt(0), which would serialise every store behind it).
+    // Normal tiles: lane holds n = nb + 4q + {0..3} of token m = mb + (lane & 15); EPI_VT: tokens mb + 4q + {0..3} of feature
+    // n = nb + (lane & 15).
+    f4 bias_cur[TN], bias_nxt[TN];
+    auto load_bias = [&](int n0, f4 (&bv)[TN]) {
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            const int n = n0 + (wn * TN + i) * 16 + q4;
-            bv[i] = n < a.N ? ld4(bias + n) : splat4(0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int n = n0 + (wn * TN + i) * 16 + q4;
-            if (n >= a.N) continue;                           // N is a multiple of 4; W rows beyond N are zero padding
-            if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
-                // read-modify-write of the f32 residual stream: all TM loads of a column tile are issued before the first
-                // store (a store to `resid` may alias the next load as far as the compiler knows, which would otherwise
-                // serialise TM x TN full memory round trips)
-                f4 old[TM];
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    int m = m0 + (wm * TM + j) * 16 + l15;
-                    m = m < a.M ? m : a.M - 1;
-                    if constexpr (EPI == EPI_RESID) old[j] = ld4(a.resid + (size_t)m * a.N + n);
-                    else old[j] = ld4(a.pos + (size_t)(m % a.L) * a.N + n);
-                }
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int m = m0 + (wm * TM + j) * 16 + l15;
-                    if (m < a.M) st4(a.resid + (size_t)m * a.N + n, old[j] + acc[i][j] + bv[i]);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-                const int m = m0 + (wm * TM + j) * 16 + l15;
-                if (m >= a.M) continue;
-                const f4 v = acc[i][j] + bv[i];
-                if constexpr (EPI == EPI_BF16) {
-                    *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(v);
-                } else if constexpr (EPI == EPI_GELU) {
-                    const f4 g = {gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
-                    *reinterpret_cast<bf16x4*>(static_cast<bf16*>(a.out) + (size_t)m * a.ldo + n) = to_bf16x4(g);
-                } else if constexpr (EPI == EPI_CONV) {
-                    const f4 r = {fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
-                    size_t row = (size_t)m;
-                    if (a.out_padded) {
-                        const int FF = a.F * a.F, bb = m / FF, yx = m - bb * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                        row = (size_t)((bb * P + y + 1) * P + x + 1);
-                    }
-                    bf16* o = static_cast<bf16*>(a.out) + grp * a.gOut;
-                    int nn = n;
-                    if (a.n_split) { const int t = n / a.n_split; o += (size_t)t * a.gOut; nn = n - t * a.n_split; }
-                    *reinterpret_cast<bf16x4*>(o + row * a.ldo + nn) = to_bf16x4(r);
-                }
+            if constexpr (EPI == EPI_VT) {
+                bv[i] = splat4(bias[n0 + (wn * TN + i) * 16 + l15]);
+            } else {
+                const int n = n0 + (wn * TN + i) * 16 + q4;
+                bv[i] = n < a.N ? ld4(bias + n) : splat4(0.f);
             }
         }
     };
+    // Epilogue through LDS: every wave owns a 4 KiB staging area (behind the pipeline stages) and moves its (TM x 16) x 64
+    // result sub-tile through it in 4 KiB chunks, so that global memory sees WHOLE rows -- 16 B per lane, 8 lanes per 128-byte
+    // bf16 row / 16 lanes per 256-byte f32 row -- instead of the accumulator layout's 8-byte pieces at a row stride (measured:
+    // those cost 12 us per 256 x 256 tile, a third of the K = 768 GEMMs).  Chunks are XOR-swizzled by row so the column-wise
+    // writes spread over the banks.  CHECK = false on tiles wholly inside M (all but the last tile row): no per-store branch.
+    static_assert(TN == 4, "a wave's sub-tile is 64 output features wide");
+    char* const ep = smem + EP_OFF + w * 4096;
+    auto epilogue_impl = [&](int m0, int n0, auto check) {
+        constexpr bool CHECK = decltype(check)::value;
+        const int mw = m0 + wm * TM * 16, nw = n0 + wn * 64;           // this wave's sub-tile origin
+        if constexpr (EPI == EPI_VT) {
+            // swapped tile: features on lanes.  Chunk = 16 features x 128 tokens (256-byte rows)
+            static_assert(EPI != EPI_VT || TM == 8, "128 tokens per row");
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    *reinterpret_cast<bf16x4a*>(ep + l15 * 256 + (((j * 2 + (q4 >> 3)) ^ l15) << 4) + (q4 & 4) * 2) = to_bf16x4(acc[i][j]);
+                lds_fence();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 4 * t + (lane >> 4), ch = lane & 15;
+                    const uint4 v = *reinterpret_cast<const uint4a*>(ep + row * 256 + ((ch ^ row) << 4));
+                    const int m = mw + ch * 8, n = nw + i * 16 + row;
+                    if (!CHECK || m < a.M) {      // M is a multiple of 8 (L is): 8 tokens never straddle a frame or the end
+                        const int f = m / a.L, tk = m - f * a.L;
+                        *reinterpret_cast<uint4*>(a.vt + ((size_t)f * a.N + n) * a.L + tk) = v;
+                    }
+                }
+                lds_fence();
+            }
+            return;
+        }
+        if (nw >= a.N) return;                                           // W rows beyond N are zero padding (BN = 64, N = 32)
+        if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
+            // f32 residual stream: chunk = 16 rows x 256 B; read-modify-write in whole rows, loads before stores
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j];
+                f4 old[4];
+                const int ch = lane & 15, r0 = lane >> 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mw + j * 16 + 4 * t + r0;
+                    const int mc = CHECK ? (m < a.M ? m : a.M - 1) : m;
+                    if constexpr (EPI == EPI_RESID) old[t] = ld4(a.resid + (size_t)mc * a.N + nw + ch * 4);
+                    else old[t] = ld4(a.pos + (size_t)(mc % a.L) * a.N + nw + ch * 4);
+                }
+                lds_fence();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 4 * t + r0, m = mw + j * 16 + row;
+                    const f4 v = *reinterpret_cast<const f4a*>(ep + row * 256 + ((ch ^ row) << 4));
+                    if (!CHECK || m < a.M) st4(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
+                }
+                lds_fence();
+            }
+            return;
+        }
+        // bf16 outputs: chunk = 32 rows x 128 B
+        bf16* obase = static_cast<bf16*>(a.out);
+        int ncol = nw;
+        if constexpr (EPI == EPI_CONV) {
+            obase += grp * a.gOut;
+            if (a.n_split) { const int t = nw / a.n_split; obase += (size_t)t * a.gOut; ncol = nw - t * a.n_split; }
+        }
+#pragma unroll
+        for (int c = 0; c < TM / 2; ++c) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int row = jj * 16 + l15;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    f4 v = acc[i][2 * c + jj];
+                    if constexpr (EPI == EPI_GELU) v = f4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                    if constexpr (EPI == EPI_CONV) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+                    *reinterpret_cast<bf16x4a*>(ep + row * 128 + (((i * 2 + (q4 >> 3)) ^ (row & 7)) << 4) + (q4 & 4) * 2) = to_bf16x4(v);
+                }
+            }
+            lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 8 * t + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4a*>(ep + row * 128 + ((ch ^ (row & 7)) << 4));
+                const int m = mw + c * 32 + row;
+                if (CHECK && m >= a.M) continue;
+                if (nw + ch * 8 >= a.N) continue;              // zero-padded weight rows (N = 32 under a 64-wide tile)
+                size_t orow = (size_t)m;
+                if constexpr (EPI == EPI_CONV) {
+                    if (a.out_padded) {
+                        const int FF = a.F * a.F, bb = m / FF, yx = m - bb * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        orow = (size_t)((bb * P + y + 1) * P + x + 1);
+                    }
+                }
+                *reinterpret_cast<uint4*>(obase + orow * a.ldo + ncol + ch * 8) = v;
+            }
+            lds_fence();
+        }
+    };
+    auto epilogue = [&](int m0, int n0) {
+        if (m0 + BM <= a.M) epilogue_impl(m0, n0, std::false_type{});
+        else epilogue_impl(m0, n0, std::true_type{});
+    };
 
     const int fr = swz_byte((lane & 15) * 64 + (lane >> 4) * 16);   // fragment byte inside a sub-tile
-    const int nk = a.K / BK;
-    // ---- persistent loop over this workgroup's tiles: the DMA of the next tile's first k-tile is issued before the
-    // epilogue of the current one, so its latency hides behind the epilogue's stores
-    int vb = blockIdx.x, m0, n0;
-    if (vb >= nwg) return;
-    tile_of(vb, m0, n0);
-    set_sources(m0, n0);
-    stage(0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (;;) {
+    auto mfma_step = [&](const char* xp, const char* wp, int stride) {     // one 32-deep k-step from LDS
+        bf16x8 fw[TN], fx[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + i * stride);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + j * stride);
+        if constexpr (EPI == EPI_VT) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto zero_acc = [&]() {          // accumulators start at the bias of their output features
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = splat4(0.f);
-        for (int kt = 0; kt < nk; ++kt) {
-            char* cur = smem + (kt & 1) * BUF_BYTES;
-            if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF_BYTES);
-            const char* xp = cur + (wm * TM * 2) * 1024 + fr;
-            const char* wp = cur + (SX + wn * TN * 2) * 1024 + fr;
+            for (int j = 0; j < TM; ++j) acc[i][j] = bias_cur[i];
+    };
+    auto roll_bias = [&]() {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 fw[TN], fx[TM];
+        for (int i = 0; i < TN; ++i) bias_cur[i] = bias_nxt[i];
+    };
+    int vb = blockIdx.x, m0, n0;
+    if (vb >= nwg) return;
+    tile_of(vb, m0, n0);
+    load_bias(n0, bias_cur);
+
+    if constexpr (PIPE4) {
+        // ---- four stages of one 32-deep k-step: [stage][X sub-tiles BM/16 | W sub-tiles BN/16] x 1 KiB
+        constexpr int RX = BM / 16, RW = BN / 16, STAGE_BYTES = (RX + RW) * 1024;
+        constexpr int NQ = (RX + RW) / NWAVES, NQX = RX / NWAVES;          // DMA instructions per wave and k-step
+        static_assert(NQ * 2 <= 63, "vmcnt immediate");
+        unsigned soff[NQ];
+        auto set_sources4 = [&](int m0, int n0) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + (i * 2 + kk) * 1024);
-#pragma unroll
-                for (int j = 0; j < TM; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + (j * 2 + kk) * 1024);
-                if constexpr (EPI == EPI_VT) {
-#pragma unroll
-                    for (int i = 0; i < TN; ++i)
-#pragma unroll
-                        for (int j = 0; j < TM; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < NQ; ++i) {
+                const int s = w + NWAVES * i;
+                if (i < NQX) {
+                    int m = m0 + s * 16 + prow;
+                    m = m < a.M ? m : a.M - 1;
+                    unsigned base;
+                    if constexpr (AMODE == A_CONV) {
+                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        base = (unsigned)(((b * P + y) * P + x) * a.C);
+                    } else {
+                        base = (unsigned)m * (unsigned)a.K;
+                    }
+                    soff[i] = base + pk;
                 } else {
-#pragma unroll
-                    for (int i = 0; i < TN; ++i)
-#pragma unroll
-                        for (int j = 0; j < TM; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                    soff[i] = (unsigned)(n0 + (s - RX) * 16 + prow) * (unsigned)a.K + pk;
                 }
             }
+        };
+        auto issue = [&](int ks) {             // DMA of k-step ks into stage ks & 3
+            unsigned kx;
+            if constexpr (AMODE == A_CONV) {
+                const int per_tap = a.C / 32, tap = ks / per_tap, c0 = (ks - tap * per_tap) * 32, r = tap / 3, sx = tap - 3 * r;
+                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
+            } else {
+                kx = (unsigned)ks * 32;
+            }
+            char* st = smem + (ks & 3) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int s = w + NWAVES * i;
+                const bf16* g = i < NQX ? X + soff[i] + kx : W + soff[i] + (unsigned)ks * 32;
+                glds16(g, st + s * 1024 + lane * 16);
+            }
+        };
+        const int nks = a.K / 32;              // a multiple of 4 (host checks K % 128 == 0): the last step sits in stage 3
+        set_sources4((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+        issue(0); issue(1); issue(2);
+        for (;;) {
+            zero_acc();
+            for (int ks = 0; ks < nks; ++ks) {
+                // the DMA group of step ks has landed once at most the two younger groups are outstanding.  At ks == 0 the
+                // queue also holds the previous tile's epilogue stores behind the three prefetched groups: drain it.
+                if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
+                else if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // every wave's part of step ks is in LDS; stage (ks - 1) & 3 is free
+                if (ks + 3 < nks) issue(ks + 3);
+                const char* st = smem + (ks & 3) * STAGE_BYTES;
+                if (!(a.dbg & 4)) mfma_step(st + (wm * TM) * 1024 + fr, st + (RX + wn * TN) * 1024 + fr, 1024);
+            }
+            // stages 0..2 were last read in steps nks-4 .. nks-2, which every wave has finished (it passed the barrier of
+            // step nks-1): the next tile's first three steps can fly while this tile's epilogue runs
+            const int cm0 = m0, cn0 = n0;
+            vb += gridDim.x;
+            const bool more = vb < nwg;
+            if (more) {
+                tile_of(vb, m0, n0);
+                set_sources4((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+                issue(0); issue(1); issue(2);
+                load_bias(n0, bias_nxt);
+            }
+            if (!(a.dbg & 8)) epilogue(cm0, cn0);
+            if (!more) break;
+            roll_bias();
+        }
+    } else {
+        const int nk = a.K / BK;
+        // ---- two buffers of one 64-deep k-tile; the DMA of the next tile's first k-tile is issued ahead of the epilogue
+        set_sources(m0, n0);
+        stage(0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (;;) {
+            zero_acc();
+            for (int kt = 0; kt < nk; ++kt) {
+                char* cur = smem + (kt & 1) * BUF_BYTES;
+                if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF_BYTES);
+                const char* xp = cur + (wm * TM * 2) * 1024 + fr;
+                const char* wp = cur + (SX + wn * TN * 2) * 1024 + fr;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) mfma_step(xp + kk * 1024, wp + kk * 1024, 2048);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // every wave has passed the barrier that ends the last k-tile: both LDS buffers are free
+            const int cm0 = m0, cn0 = n0;
+            vb += gridDim.x;
+            const bool more = vb < nwg;
+            if (more) {
+                tile_of(vb, m0, n0);
+                set_sources(m0, n0);
+                stage(0, smem);
+                load_bias(n0, bias_nxt);
+            }
+            epilogue(cm0, cn0);
+            if (!more) break;
+            roll_bias();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        // every wave has passed the barrier that ends the last k-tile: both LDS buffers are free
-        const int cm0 = m0, cn0 = n0;
-        vb += gridDim.x;
-        const bool more = vb < nwg;
-        if (more) {
-            tile_of(vb, m0, n0);
-            set_sources(m0, n0);
-            stage(0, smem);
-        }
-        epilogue(cm0, cn0);
-        if (!more) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 }
 
 template <int BM, int BN>
-constexpr int lds_bytes() { return 2 * (BM / 16 * 2 + BN / 16 * 2) * 1024; }
+constexpr int lds_bytes() { return 2 * (BM / 16 * 2 + BN / 16 * 2) * 1024 + NWAVES * 4096; }   // pipeline stages + epilogue staging
 
 }  // namespace vbg

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -106,11 +107,14 @@ int num_cus() {
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E) {
+    static const int dbg = [] { const char* v = std::getenv("VB_DBG"); return v ? std::atoi(v) : 0; }();
+    vbg::Args ad = a;
+    ad.dbg = dbg;
     // persistent workgroups: one per CU, each walks tiles blockIdx.x, blockIdx.x + grid, ...
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const int tiles = std::min(ntiles, std::max(8, num_cus() / groups / 8 * 8));
     constexpr int lds = vbg::lds_bytes<BM, BN>();
-    hipLaunchKernelGGL((vbg::gemm_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(tiles, groups), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((vbg::gemm_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(tiles, groups), dim3(512), lds, st, ad);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }

@@ -206,6 +206,10 @@ __global__ __launch_bounds__(64) void decode_kernel(const float* __restrict__ sc
         argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
         argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
     }
+    // a score map of NaNs never beats the initial value: keep the gathers in bounds (the box then inherits the NaNs of the
+    // maps at index 0 instead of reading far outside them)
+    if (i0 >= n) i0 = 0;
+    if (i1 >= n) i1 = 0;
     if (lane == 0) {
         const float fF = (float)F;
         const float* sz = size + (size_t)b * 2 * n;
