@@ -33,6 +33,10 @@
 
 #include "vt_common.h"
 
+#ifndef VB_GEMM_LINE2
+#define VB_GEMM_LINE2 1
+#endif
+
 namespace vbg {
 
 typedef __bf16 bf16;
@@ -105,7 +109,13 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     static_assert((SX + SW) % NWAVES == 0 && SX % NWAVES == 0, "panel split");
     constexpr int NSX = SX / NWAVES;
     constexpr int BUF_BYTES = (SX + SW) * 1024;
-    constexpr bool PIPE4 = (BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0;     // 4-stage pipeline (256 x 256)
+    constexpr bool WIDE = (BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0;      // the 256 x 256 tile
+    // Two fill paths for the wide tile (A/B-tested on hardware; LINE2 is the shipped one):
+    //   LINE2: two stages of one 64-deep k-tile; a DMA piece is 8 rows x 128 B, i.e. WHOLE cache lines (half the L2 requests
+    //          per byte of the 16-row x 64-byte pieces), XOR-swizzled by row (chunk ^ row): conflict-free ds_read_b128.
+    //   PIPE4: four stages of one 32-deep k-step in 16-row x 64-byte pieces (st_16x32), counted vmcnt.
+    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2;
+    constexpr bool PIPE4 = WIDE && !LINE2;
     constexpr int EP_OFF = 2 * BUF_BYTES;                                           // epilogue staging: 8 waves x 4 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -322,7 +332,88 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     tile_of(vb, m0, n0);
     load_bias(n0, bias_cur);
 
-    if constexpr (PIPE4) {
+    if constexpr (LINE2) {
+        // ---- two stages of one 64-deep k-tile in whole-line pieces: [stage][X pieces BM/8 | W pieces BN/8] x 1 KiB,
+        // piece = 8 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ r
+        constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
+        constexpr int NQ = (PX + PW) / NWAVES, NQX = PX / NWAVES;
+        static_assert(2 * STAGE_BYTES == EP_OFF, "stages end where the epilogue staging begins");
+        const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;       // DMA: row in piece, k element of this lane's 16 bytes
+        unsigned soff[NQ];
+        auto set_sources_l = [&](int m0, int n0) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int p = w + NWAVES * i;
+                if (i < NQX) {
+                    int m = m0 + p * 8 + drow;
+                    m = m < a.M ? m : a.M - 1;
+                    unsigned base;
+                    if constexpr (AMODE == A_CONV) {
+                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        base = (unsigned)(((b * P + y) * P + x) * a.C);
+                    } else {
+                        base = (unsigned)m * (unsigned)a.K;
+                    }
+                    soff[i] = base + dk;
+                } else {
+                    soff[i] = (unsigned)(n0 + (p - PX) * 8 + drow) * (unsigned)a.K + dk;
+                }
+            }
+        };
+        auto issue_l = [&](int kt, char* st) {
+            unsigned kx;
+            if constexpr (AMODE == A_CONV) {
+                const int per_tap = a.C / BK, tap = kt / per_tap, c0 = (kt - tap * per_tap) * BK, r = tap / 3, sx = tap - 3 * r;
+                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
+            } else {
+                kx = (unsigned)kt * BK;
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int p = w + NWAVES * i;
+                const bf16* g = i < NQX ? X + soff[i] + kx : W + soff[i] + (unsigned)kt * BK;
+                glds16(g, st + p * 1024 + lane * 16);
+            }
+        };
+        // fragment of 16-row tile T, k-step kk: row r16 = lane & 15 -> piece 2T + (r16 >> 3), row r16 & 7, chunk (4 kk + q) ^ row
+        const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
+        const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
+        const int nk = a.K / BK;
+        set_sources_l((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+        issue_l(0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (;;) {
+            zero_acc();
+            for (int kt = 0; kt < nk; ++kt) {
+                char* cur = smem + (kt & 1) * STAGE_BYTES;
+                if (kt + 1 < nk) issue_l(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
+                if (!(a.dbg & 4)) {
+                    mfma_step(cur + (wm * TM * 2) * 1024 + fk0, cur + (PX + wn * TN * 2) * 1024 + fk0, 2048);
+                    mfma_step(cur + (wm * TM * 2) * 1024 + fk1, cur + (PX + wn * TN * 2) * 1024 + fk1, 2048);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            // Every wave has passed the barrier that ends the last k-tile: both stages are free; the next tile's first k-tile
+            // and bias are requested before the epilogue.  (Measured and rejected: requesting TWO k-tiles here and replacing
+            // the drain below by a counted vmcnt that leaves the epilogue's stores in flight -- qk 205 -> 237 us, v 107 -> 139.)
+            const int cm0 = m0, cn0 = n0;
+            vb += gridDim.x;
+            const bool more = vb < nwg;
+            if (more) {
+                tile_of(vb, m0, n0);
+                set_sources_l((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+                issue_l(0, smem);
+                load_bias(n0, bias_nxt);
+            }
+            if (!(a.dbg & 8)) epilogue(cm0, cn0);
+            if (!more) break;
+            roll_bias();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else if constexpr (PIPE4) {
         // ---- four stages of one 32-deep k-step: [stage][X sub-tiles BM/16 | W sub-tiles BN/16] x 1 KiB
         constexpr int RX = BM / 16, RW = BN / 16, STAGE_BYTES = (RX + RW) * 1024;
         constexpr int NQ = (RX + RW) / NWAVES, NQX = RX / NWAVES;          // DMA instructions per wave and k-step
