@@ -396,8 +396,14 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 __syncthreads();
             }
             // Every wave has passed the barrier that ends the last k-tile: both stages are free; the next tile's first k-tile
-            // and bias are requested before the epilogue.  (Measured and rejected: requesting TWO k-tiles here and replacing
-            // the drain below by a counted vmcnt that leaves the epilogue's stores in flight -- qk 205 -> 237 us, v 107 -> 139.)
+            // and bias are requested before the epilogue.  Measured and rejected on this loop (B = 256, us per launch):
+            //   * requesting TWO k-tiles here + a counted vmcnt that leaves the epilogue's stores in flight: qk 205 -> 237, v 107 -> 139
+            //   * the DMA pieces issued one by one between groups of 8 MFMAs (sched_barrier-pinned) instead of as a burst:
+            //     qk 205 -> 213, fc1 447 -> 448 (and 16-20 B of scratch)
+            //   * PIPE4 with waves 4-7 issuing their DMA share after their MFMAs (stagger): qk 216, fc1 473, conv1 625
+            // What the VB_DBG experiments say (profiles/r2_vitb_timing_experiments.txt): the DMA pipeline alone runs at
+            // ~48 GB/s per CU (1.4 us per 64 KiB k-tile) whatever the piece shape or depth, the MFMAs alone need 0.85 us, and
+            // together they take 1.8 us: the two do not overlap well inside one instruction stream per wave.
             const int cm0 = m0, cn0 = n0;
             vb += gridDim.x;
             const bool more = vb < nwg;

@@ -304,10 +304,12 @@ size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth) {
 }
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode) {
+    if (zcache_mode != 0 && !ZC)
+        return fail(VT_ERR_STATE, "the template cache needs the default block kernel (VT_BLOCKS_BAL = 1)");
     const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth);
-    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
                        resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode);
     HIP_TRY(hipGetLastError());
     return VT_OK;
@@ -318,12 +320,14 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     switch (m->L / 16) {
         case 5:
-            if (m->blocks_bal) return launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
+            if (m->blocks_bal) return zc ? launch_blocks<5, 8, 1, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                                         : launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
             return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                                   : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
-            return m->blocks_bal ? launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid, zc)
-                                 : launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid, zc);
+            if (m->blocks_bal) return zc ? launch_blocks<20, 8, 3, false, false, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                                         : launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid, zc);
+            return launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         default: return fail(VT_ERR_ARG, "unsupported token count " + std::to_string(m->L));
     }
 }
@@ -542,6 +546,12 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
         (void)small_bytes;
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8>),

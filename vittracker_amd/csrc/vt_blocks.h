@@ -191,7 +191,7 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
 //     fc2         K-split: guest g contracts its own hidden tiles -> partial in LDS; summed (36)
 // Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream that
 // fills the owner's waits (f32 MFMA and VALU issue add up even across waves: tools/src/probe_overlap.hip).
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false>
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false>   // ZC: template-cache variant (config 5)
 __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            const bool z_tile = blk == 0 && 16 * T < len_z;       // wave-uniform
+            const bool z_tile = ZC && blk == 0 && 16 * T < len_z;       // wave-uniform; compiled out of the default kernel
             f4* const zc = reinterpret_cast<f4*>(zcache) + (((size_t)b * (len_z >> 4) + T) * 3 * NC) * 64 + lane;
             if (T < NOWN && T != dbg_skip_tile && z_tile && zcache_mode == 2) {
 #pragma unroll
