@@ -64,57 +64,84 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     const int l15 = lane & 15, q = lane >> 4;
     const int fr = vbg::swz_byte(l15 * 64 + q * 16);
     constexpr float LOG2E = 1.4426950408889634f;
-    for (int qt = w; qt < G::NT; qt += 4) {
+    // NQ query tiles at once: every K / V^T fragment read from LDS feeds NQ MFMAs.  With one tile per pass the kernel issues one
+    // ds_read_b128 per MFMA -- 256 B/clk/CU for four SIMDs' worth of 16-cycle MFMAs is exactly the LDS bandwidth, so it was
+    // LDS-bound; two tiles halve the reads (a wave's five tiles go as 2 + 2 + 1).
+    auto pass = [&](auto nq_tag, int qt0, int qt1) {
+        constexpr int NQ = decltype(nq_tag)::value;
+        const int qts[2] = {qt0, qt1};
         // the K / V^T fragments do not depend on the query tile: without this the compiler hoists all 80 ds_reads
         // (320 VGPRs) out of the loop and spills them
         int frq = fr;
         asm volatile("" : "+v"(frq));
-        bf16x8 qfrag[G::KS];
+        bf16x8 qfrag[NQ][G::KS];
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks)
-            qfrag[ks] = *reinterpret_cast<const bf16x8*>(qf + (size_t)(qt * 16 + l15) * 2 * C + ks * 32 + q * 8);
-        f4 S[G::NT];
-#pragma unroll
-        for (int t = 0; t < G::NT; ++t) {
-            S[t] = splat4(0.f);
+        for (int u = 0; u < NQ; ++u)
 #pragma unroll
             for (int ks = 0; ks < G::KS; ++ks)
-                S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Kimg + (t * G::KS + ks) * 1024 + frq),
-                                                               qfrag[ks], S[t], 0, 0, 0);
-        }
-        float mx = hmax4(S[0]);
-#pragma unroll
-        for (int t = 1; t < G::NT; ++t) mx = fmaxf(mx, hmax4(S[t]));
-        mx = quad_max(mx);
-        const float mb = mx * LOG2E;
-        float sum = 0.f;
+                qfrag[u][ks] = *reinterpret_cast<const bf16x8*>(qf + (size_t)(qts[u] * 16 + l15) * 2 * C + ks * 32 + q * 8);
+        f4 S[NQ][G::NT];
 #pragma unroll
         for (int t = 0; t < G::NT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(S[t][r], LOG2E, -mb));
-                S[t][r] = p;
-                sum += p;
+            for (int u = 0; u < NQ; ++u) S[u][t] = splat4(0.f);
+#pragma unroll
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const bf16x8 kf8 = *reinterpret_cast<const bf16x8*>(Kimg + (t * G::KS + ks) * 1024 + frq);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) S[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf8, qfrag[u][ks], S[u][t], 0, 0, 0);
             }
         }
-        sum = quad_sum(sum);
-        f4 O[G::DT];
+        float inv[NQ];
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) O[dt] = splat4(0.f);
+        for (int u = 0; u < NQ; ++u) {
+            float mx = hmax4(S[u][0]);
+#pragma unroll
+            for (int t = 1; t < G::NT; ++t) mx = fmaxf(mx, hmax4(S[u][t]));
+            mx = quad_max(mx);
+            const float mb = mx * LOG2E;
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < G::NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[u][t][r], LOG2E, -mb));
+                    S[u][t][r] = p;
+                    sum += p;
+                }
+            }
+            inv[u] = 1.0f / quad_sum(sum);
+        }
+        f4 O[NQ][G::DT];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) O[u][dt] = splat4(0.f);
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
-            const bf16x4 lo = vbg::to_bf16x4(S[2 * c]), hi = vbg::to_bf16x4(S[2 * c + 1]);
-            const bf16x8 p = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            bf16x8 p[NQ];
 #pragma unroll
-            for (int dt = 0; dt < G::DT; ++dt)
-                O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(Vimg + (dt * G::NC + c) * 1024 + frq), p,
-                                                                O[dt], 0, 0, 0);
+            for (int u = 0; u < NQ; ++u) {
+                const bf16x4 lo = vbg::to_bf16x4(S[u][2 * c]), hi = vbg::to_bf16x4(S[u][2 * c + 1]);
+                p[u] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) {
+                const bf16x8 vf8 = *reinterpret_cast<const bf16x8*>(Vimg + (dt * G::NC + c) * 1024 + frq);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) O[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf8, p[u], O[u][dt], 0, 0, 0);
+            }
         }
-        const float inv = 1.0f / sum;
-        bf16* o = out + (size_t)(f * L + qt * 16 + l15) * C + h * HD + q * 4;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = vbg::to_bf16x4(O[dt] * splat4(inv));
-    }
+        for (int u = 0; u < NQ; ++u) {
+            bf16* o = out + (size_t)(f * L + qts[u] * 16 + l15) * C + h * HD + q * 4;
+#pragma unroll
+            for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = vbg::to_bf16x4(O[u][dt] * splat4(inv[u]));
+        }
+    };
+    int qt = w;
+    for (; qt + 4 < G::NT; qt += 8) pass(std::integral_constant<int, 2>{}, qt, qt + 4);
+    if (qt < G::NT) pass(std::integral_constant<int, 1>{}, qt, qt);
 }
 
 }  // namespace vba
