@@ -39,6 +39,8 @@ print("OK", worst)
 """ % {"root": ROOT}
 
 VARIANTS = {
+    # the fixtures' batches are small: by default they run the multi-workgroup forms, so the large-batch forms are forced here
+    "large_batch_forms_forced": {"VT_STEM_FUSED": "1", "VT_STEM_PIPE": "1", "VT_HEAD_FUSED": "1"},
     "two_kernel_stem": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0"},
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},

@@ -81,9 +81,12 @@ struct vt_model {
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
     int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
-    int head_fused = 1;    // F = 8: head_fused_kernel (towers + decode in one workgroup per frame)
-    int stem_pipe = 1;     // G256: stem_pipe_kernel (layers 1 + 2 per frame) instead of stem_a
-    int stem_fused = 1;    // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b
+    // Kernel form per stage: 1 / 0 force it, -1 (default) = by batch size.  The one-workgroup-per-frame forms win once the batch
+    // fills the chip; below that the multi-workgroup forms spread a frame over several CUs (measured, us per step, tools/
+    // small_batch_sweep.py: G128 B=1 97.6 -> 81.1, B=64 100.4 -> 86.1; G256 B=1 337 -> 287; crossovers at the thresholds below).
+    int head_fused = -1;   // F = 8: head_fused_kernel (towers + decode in one workgroup per frame); auto: B > 176
+    int stem_pipe = -1;    // G256: stem_pipe_kernel (layers 1 + 2 per frame) instead of stem_a; auto: B > 176
+    int stem_fused = -1;   // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b; auto: B > 80
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
@@ -253,7 +256,9 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
             3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64)
             return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
     }
-    if (m->stem_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
+    const bool want_fused = m->stem_fused < 0 ? B > 80 : m->stem_fused != 0;
+    const bool want_pipe = m->stem_pipe < 0 ? B > 176 : m->stem_pipe != 0;
+    if (want_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
         hipLaunchKernelGGL(vts::stem_fused_kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p,
                            m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p,
@@ -261,8 +266,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         HIP_TRY(hipGetLastError());
         return VT_OK;
     }
-    const bool pipe = m->stem_pipe && Tx == 256 && Tz == 128;
-    if (zmode != 0 && !pipe) return fail(VT_ERR_STATE, "the template cache needs the default stem kernels (VT_STEM_FUSED / VT_STEM_PIPE = 1)");
+    const bool pipe = want_pipe && Tx == 256 && Tz == 128;
     if (pipe) {   // layers 1 + 2 of a frame in one workgroup (two wave groups half a period apart); stem_b follows
         constexpr size_t lds_p = vts::PipeGeo<256, 128>::LDS_BYTES;
         hipLaunchKernelGGL((vts::stem_pipe_kernel<256, 128>), dim3(B), dim3(1024), lds_p, st, z, x,
@@ -270,10 +274,14 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         HIP_TRY(hipGetLastError());
     }
     vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
+    // zmode (template cache): a crop that is not wanted gets zero bands -- stem_a / stem_b index their workgroups by
+    // (frame, band of x | band of z), so its workgroups simply do not exist
     // fused form: band k of both crops in one workgroup, when the template band then has exactly one
     // layer-2 tile per wave and the workgroup count fills whole rounds of 4 per CU better than the split form
     const int r2z_f = (Tz / 4) / ax.bands;
-    const bool fuse = m->stem_fuse && r2z_f >= 1 && r2z_f * ax.bands == Tz / 4 && r2z_f * (Tz / 4) == 64;
+    const bool fuse = zmode == 0 && m->stem_fuse && r2z_f >= 1 && r2z_f * ax.bands == Tz / 4 && r2z_f * (Tz / 4) == 64;
+    if (zmode == 1) az.bands = 0;
+    if (zmode == 2) ax.bands = 0;
     if (pipe) {
     } else if (fuse) {
         az.r2 = r2z_f; az.bands = ax.bands;
@@ -348,7 +356,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
     float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
-    if (m->F == 8 && m->head_fused) {
+    if (m->F == 8 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
         // towers + both decodes in one workgroup per frame
         hipLaunchKernelGGL(vth::head_fused_kernel<8>, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p,
                            m->window.p, score, size, offset, pred, hann, conf, m->skip_head);
@@ -509,9 +517,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
-    m->stem_fused = env_int("VT_STEM_FUSED", 1);
-    m->stem_pipe = env_int("VT_STEM_PIPE", 1);
-    m->head_fused = env_int("VT_HEAD_FUSED", 1);
+    m->stem_fused = env_int("VT_STEM_FUSED", -1);
+    m->stem_pipe = env_int("VT_STEM_PIPE", -1);
+    m->head_fused = env_int("VT_HEAD_FUSED", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
