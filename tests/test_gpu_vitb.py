@@ -122,6 +122,32 @@ def test_vitb_persistent_workgroups_large_batch():
             assert torch.equal(getattr(part, k), getattr(full, k)[i0:i0 + 4]), (i0, k)
 
 
+def test_vitb_replays_are_bit_identical_under_load():
+    """Race screen for the GEMM's LDS pipeline / staged epilogue and the attention kernel: 12 replays of a batch-64 step (every
+    GEMM walks several tiles per workgroup at the larger N) must be bit-identical, with another stream hammering HBM."""
+    import torch
+    from vittracker_amd import synth
+    sd = synth.synth_vitb_state_dict(26)
+    B = 64
+    z, x = synth.synth_inputs(9, B, 128, 256)
+    m = _model(sd, B)
+    zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+    graph, out = m.capture(zd, xd)
+    graph.launch()
+    torch.cuda.synchronize()
+    ref = {k: getattr(out, k).clone() for k in ("score_map", "size_map", "offset_map", "hann_boxes")}
+    noise = torch.empty(64 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                noise.mul_(1.0001)
+        graph.launch()
+        torch.cuda.synchronize()
+        for k, v in ref.items():
+            assert torch.equal(getattr(out, k), v), (it, k)
+
+
 def test_decode_of_a_nan_map_stays_in_bounds():
     import torch
     from vittracker_amd import native, synth

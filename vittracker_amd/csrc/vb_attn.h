@@ -58,8 +58,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         const int dt = s / G::NC, c = s - dt * G::NC;
         vbg::glds16(vf + (size_t)(dt * 16 + prow) * L + c * 32 + pk, Vimg + s * 1024 + lane * 16);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // K is needed first: wait for this wave's K pieces only (the V^T pieces, issued after them, stay in flight through the
+    // first q.k pass) -- vmcnt counts in issue order
+    constexpr int VPW = (G::V_SUB + 3) / 4;                 // V^T pieces per wave (upper bound: waves with fewer wait longer)
+    static_assert(G::V_SUB % 4 == 0 && G::K_SUB % 4 == 0, "pieces divide over the four waves");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VPW) : "memory");
     __syncthreads();
+    bool v_ready = false;
 
     const int l15 = lane & 15, q = lane >> 4;
     const int fr = vbg::swz_byte(l15 * 64 + q * 16);
@@ -117,6 +122,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         for (int u = 0; u < NQ; ++u)
 #pragma unroll
             for (int dt = 0; dt < G::DT; ++dt) O[u][dt] = splat4(0.f);
+        if (!v_ready) {                      // first pass only (wave-uniform): V^T has had the whole q.k + softmax phase to land
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            v_ready = true;
+        }
 #pragma unroll
         for (int c = 0; c < G::NC; ++c) {
             bf16x8 p[NQ];
