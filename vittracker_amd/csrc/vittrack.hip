@@ -796,7 +796,7 @@ int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const 
     if (!m || !frames_dev || !states_dev || !crops_dev || !resize_factor_dev || !mean3 || !std3)
         return fail(VT_ERR_ARG, "null argument");
     if (B < 1 || H < 1 || W < 1 || out_size < 1 || !(factor > 0.0)) return fail(VT_ERR_ARG, "bad crop arguments");
-    dim3 grid((out_size * out_size + 255) / 256, B);
+    dim3 grid((out_size * ((out_size + 3) / 4) + 255) / 256, B);
     hipLaunchKernelGGL(vtt::crop_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), frames_dev, H, W,
                        states_dev, factor, out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], crops_dev,
                        resize_factor_dev);

@@ -34,23 +34,30 @@ __device__ __forceinline__ void lin_coeff(int d, int src, double scale, int& s0,
     s1 = s + 1 < src ? s + 1 : src - 1;
 }
 
-// grid (ceil(T*T/256), B); frames (B,H,W,3) uint8; states (B,4) double [x,y,w,h]; out (B,3,T,T) float.
+// grid (ceil(T * ceil(T/4) / 256), B); frames (B,H,W,3) uint8; states (B,4) double [x,y,w,h]; out (B,3,T,T) float.
+// One thread = four consecutive output pixels of a row (all three channels): the vertical coefficients are computed once,
+// and a channel's four values leave as ONE 16-byte store when T is a multiple of 4 (the crop sizes the tracker uses are:
+// 64 / 128 / 256), i.e. whole 256-byte row segments per quarter-wave instead of 4-byte stores.
 __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restrict__ frames, int H, int W,
                                                    const double* __restrict__ states, double factor, int T,
                                                    float m0, float m1, float m2, float s0, float s1, float s2,
                                                    float* __restrict__ out, double* __restrict__ resize_factor) {
     const int b = blockIdx.y;
     const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
-    int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
+    const int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
+    const int T4 = (T + 3) >> 2;                      // pixel groups per row
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     if (!(crop_sz >= 1)) {
         // The reference raises 'Too small bounding box.' here (processing_utils.py:33-34).  A kernel cannot
         // raise: the crop and its resize factor are poisoned with NaN, so every box derived from them is NaN and
         // the caller sees it (BatchedVitTracker checks user-supplied boxes on the host before they get here; boxes
         // produced by vt_update_state are at least `margin` wide and never take this branch).
-        const int i0 = blockIdx.x * 256 + threadIdx.x;
-        if (i0 == 0) resize_factor[b] = __builtin_nan("");
-        if (i0 < T * T)
-            for (int c = 0; c < 3; ++c) out[((size_t)b * 3 + c) * T * T + i0] = __builtin_nanf("");
+        if (idx == 0) resize_factor[b] = __builtin_nan("");
+        if (idx < T * T4) {
+            const int oy = idx / T4, ox0 = (idx - oy * T4) * 4;
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 4 && ox0 + k < T; ++k) out[(((size_t)b * 3 + c) * T + oy) * T + ox0 + k] = __builtin_nanf("");
+        }
         return;
     }
     const int x1 = (int)rint(bx + 0.5 * bw - crop_sz * 0.5);     // Python round(): half to even
@@ -60,35 +67,55 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     // columns on the right, i.e. drops the last image column when the crop reaches the border)
     const int vx0 = x1 < 0 ? 0 : x1, vx1 = x2 - (x2 - W + 1 > 0 ? x2 - W + 1 : 0);
     const int vy0 = y1 < 0 ? 0 : y1, vy1 = y2 - (y2 - H + 1 > 0 ? y2 - H + 1 : 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) resize_factor[b] = (double)T / (double)crop_sz;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= T * T) return;
-    const int oy = idx / T, ox = idx - oy * T;
+    if (idx == 0) resize_factor[b] = (double)T / (double)crop_sz;
+    if (idx >= T * T4) return;
+    const int oy = idx / T4, ox0 = (idx - oy * T4) * 4;
     const double scale = (double)crop_sz / (double)T;
-    int sx0, sx1, ax0, ax1, sy0, sy1, by0, by1;
-    lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0, ax1);
+    int sy0, sy1, by0, by1;
     lin_coeff(oy, crop_sz, scale, sy0, sy1, by0, by1);
     const unsigned char* fr = frames + (size_t)b * H * W * 3;
-    auto px = [&](int cy, int cx, int c) -> int {      // pixel (cy, cx) of the zero-padded crop
-        const int yy = y1 + cy, xx = x1 + cx;
-        return (yy >= vy0 && yy < vy1 && xx >= vx0 && xx < vx1) ? (int)fr[((size_t)yy * W + xx) * 3 + c] : 0;
-    };
+    const int yy0 = y1 + sy0, yy1 = y1 + sy1;
+    const bool vr0 = yy0 >= vy0 && yy0 < vy1, vr1 = yy1 >= vy0 && yy1 < vy1;
+    const unsigned char* row0 = fr + (size_t)(vr0 ? yy0 : 0) * W * 3;
+    const unsigned char* row1 = fr + (size_t)(vr1 ? yy1 : 0) * W * 3;
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    float res[3][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = ox0 + k < T ? ox0 + k : T - 1;
+        int sx0, sx1, ax0, ax1;
+        lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0, ax1);
+        const int xx0 = x1 + sx0, xx1 = x1 + sx1;
+        const bool vc0 = xx0 >= vx0 && xx0 < vx1, vc1 = xx1 >= vx0 && xx1 < vx1;
+        const int o0 = (vc0 ? xx0 : 0) * 3, o1 = (vc1 ? xx1 : 0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // pixel (cy, cx) of the zero-padded crop: the frame inside the valid range, 0 outside
+            const int p00 = vr0 && vc0 ? (int)row0[o0 + c] : 0, p01 = vr0 && vc1 ? (int)row0[o1 + c] : 0;
+            const int p10 = vr1 && vc0 ? (int)row1[o0 + c] : 0, p11 = vr1 && vc1 ? (int)row1[o1 + c] : 0;
+            const int r0 = p00 * ax0 + p01 * ax1;
+            const int r1 = p10 * ax0 + p11 * ax1;
+            int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            // torch's CUDA `tensor / 255.0` multiplies by the float reciprocal (div_true with a CPU scalar);
+            // Preprocessor.process runs on the GPU, so that is the reference arithmetic
+            // Three separately rounded ops, as three torch kernels: the empty asm keeps hipcc from
+            // contracting the multiply and the subtraction into one fma (the _rn intrinsics do not).
+            float scaled = (float)v * (1.0f / 255.0f);
+            asm volatile("" : "+v"(scaled));
+            float centred = scaled - mean[c];
+            asm volatile("" : "+v"(centred));
+            res[c][k] = centred / stdv[c];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const int r0 = px(sy0, sx0, c) * ax0 + px(sy0, sx1, c) * ax1;
-        const int r1 = px(sy1, sx0, c) * ax0 + px(sy1, sx1, c) * ax1;
-        int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        // torch's CUDA `tensor / 255.0` multiplies by the float reciprocal (div_true with a CPU scalar);
-        // Preprocessor.process runs on the GPU, so that is the reference arithmetic
-        // Three separately rounded ops, as three torch kernels: the empty asm keeps hipcc from
-        // contracting the multiply and the subtraction into one fma (the _rn intrinsics do not).
-        float scaled = (float)v * (1.0f / 255.0f);
-        asm volatile("" : "+v"(scaled));
-        float centred = scaled - mean[c];
-        asm volatile("" : "+v"(centred));
-        out[(((size_t)b * 3 + c) * T + oy) * T + ox] = centred / stdv[c];
+        float* o = out + (((size_t)b * 3 + c) * T + oy) * T + ox0;
+        if ((T & 3) == 0) {
+            st4(o, f4{res[c][0], res[c][1], res[c][2], res[c][3]});
+        } else {
+            for (int k = 0; k < 4 && ox0 + k < T; ++k) o[k] = res[c][k];
+        }
     }
 }
 
