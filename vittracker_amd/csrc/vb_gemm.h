@@ -75,6 +75,8 @@ struct Args {
     long long gX, gW, gOut;
     int gBias;
     int n_split;          // EPI_CONV with towers concatenated along N: columns per tower (0 = none); tower t writes out + t * gOut
+    int rb;               // tile order: > 1 = tiles are walked in blocks of `rb` tile rows, column by column inside a block (so the
+                          // 32 concurrent tiles of an XCD are ~rb rows x 32 / rb columns); 0 / 1 = row-major
     int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
                           // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
                           // 4 = no MFMAs, 8 = no epilogue
@@ -131,9 +133,18 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     auto tile_of = [&](int vb, int& m0, int& n0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int tm = t / tiles_n;
+        int tm, tn;
+        if (a.rb > 1) {
+            const int per = a.rb * tiles_n, blk = t / per, rem = t - blk * per;
+            const int left = tiles_m - blk * a.rb, rows = left < a.rb ? left : a.rb;
+            tn = rem / rows;
+            tm = blk * a.rb + rem - tn * rows;
+        } else {
+            tm = t / tiles_n;
+            tn = t - tm * tiles_n;
+        }
         m0 = tm * BM;
-        n0 = (t - tm * tiles_n) * BN;
+        n0 = tn * BN;
     };
     // ---- per-lane DMA sources of this wave's sub-tiles (element offsets at k-tile 0)
     const int pl = swz_byte(lane * 16), prow = pl >> 6, pk = (pl & 63) >> 1;     // row in sub-tile, k element in sub-tile

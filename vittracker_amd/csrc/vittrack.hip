@@ -260,17 +260,33 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     const bool want_pipe = m->stem_pipe < 0 ? B > 176 : m->stem_pipe != 0;
     if (want_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
-        hipLaunchKernelGGL(vts::stem_fused_kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p,
-                           m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p,
-                           m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, zmode);
+        const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
+                               m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p,
+                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps);
+        };
+        if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
+        if (diag) go(&vts::stem_fused_kernel<0, true>);
+        else if (zmode == 0) go(&vts::stem_fused_kernel<0, false>);
+        else if (zmode == 1) go(&vts::stem_fused_kernel<1, false>);
+        else go(&vts::stem_fused_kernel<2, false>);
         HIP_TRY(hipGetLastError());
         return VT_OK;
     }
     const bool pipe = want_pipe && Tx == 256 && Tz == 128;
     if (pipe) {   // layers 1 + 2 of a frame in one workgroup (two wave groups half a period apart); stem_b follows
         constexpr size_t lds_p = vts::PipeGeo<256, 128>::LDS_BYTES;
-        hipLaunchKernelGGL((vts::stem_pipe_kernel<256, 128>), dim3(B), dim3(1024), lds_p, st, z, x,
-                           m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps, zmode);
+        const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds_p, st, z, x, m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p,
+                               m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps);
+        };
+        if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
+        if (diag) go(&vts::stem_pipe_kernel<256, 128, 0, true>);
+        else if (zmode == 0) go(&vts::stem_pipe_kernel<256, 128, 0, false>);
+        else if (zmode == 1) go(&vts::stem_pipe_kernel<256, 128, 1, false>);
+        else go(&vts::stem_pipe_kernel<256, 128, 2, false>);
         HIP_TRY(hipGetLastError());
     }
     vts::CropA ax{x, act_x, Tx, px.r2, (Tx / 4) / px.r2}, az{z, act_z, Tz, pz.r2, (Tz / 4) / pz.r2};
@@ -297,8 +313,12 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, zmode == 2 ? 0 : (Tx / 16) / px.r4, m->len_z};
     vts::CropB bz{act_z, m->pos_z.p, Tz / 4, pz.r4, zmode == 1 ? 0 : (Tz / 16) / pz.r4, 0};
     const size_t lds_b = std::max(vts::stem_b_lds_bytes(Tx / 4, px.r4), vts::stem_b_lds_bytes(Tz / 4, pz.r4));
-    hipLaunchKernelGGL(vts::stem_b_kernel, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
-                       m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, m->skip_stem_b);
+    if (m->skip_stem_b)
+        hipLaunchKernelGGL(vts::stem_b_kernel<true>, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
+                           m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, m->skip_stem_b);
+    else
+        hipLaunchKernelGGL(vts::stem_b_kernel<false>, dim3(B * (bx.bands + bz.bands)), dim3(256), lds_b, st, bx, bz, m->stem_w[2].p,
+                           m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, tokens, m->L, m->skip_stem_b);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -358,18 +378,30 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
     if (m->F == 8 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
         // towers + both decodes in one workgroup per frame
-        hipLaunchKernelGGL(vth::head_fused_kernel<8>, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p,
-                           m->window.p, score, size, offset, pred, hann, conf, m->skip_head);
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
+                               size, offset, pred, hann, conf, m->skip_head);
+        };
+        if (m->skip_head) go(&vth::head_fused_kernel<8, true>);
+        else go(&vth::head_fused_kernel<8, false>);
         HIP_TRY(hipGetLastError());
         return VT_OK;
     }
     if (m->F == 8) {
-        hipLaunchKernelGGL(vth::head_towers_kernel<8>, dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st,
-                           feat, m->head.p, score, size, offset, m->skip_head);
+        if (m->skip_head)
+            hipLaunchKernelGGL((vth::head_towers_kernel<8, 4, true>), dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st, feat, m->head.p,
+                               score, size, offset, m->skip_head);
+        else
+            hipLaunchKernelGGL((vth::head_towers_kernel<8, 4, false>), dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st, feat, m->head.p,
+                               score, size, offset, m->skip_head);
     } else if (m->F == 16) {
         // 129 KB of LDS per tower = one workgroup per CU: 8 waves give every SIMD two instruction streams
-        hipLaunchKernelGGL((vth::head_towers_kernel<16, 8>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES,
-                           st, feat, m->head.p, score, size, offset, m->skip_head);
+        if (m->skip_head)
+            hipLaunchKernelGGL((vth::head_towers_kernel<16, 8, true>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES, st, feat,
+                               m->head.p, score, size, offset, m->skip_head);
+        else
+            hipLaunchKernelGGL((vth::head_towers_kernel<16, 8, false>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES, st, feat,
+                               m->head.p, score, size, offset, m->skip_head);
     } else {
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
     }
@@ -461,6 +493,24 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
 }  // namespace
 
 // =========================================================================================== ABI
+// dynamic-LDS limits of every instantiation of the two one-workgroup-per-frame stem kernels
+static hipError_t allow_stem_lds() {
+    hipError_t e = hipSuccess;
+    auto allow = [&](auto kernel, int bytes) {
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    };
+    constexpr int lp = (int)vts::PipeGeo<256, 128>::LDS_BYTES, lf = vts::FusedGeo::LDS_BYTES;
+    allow(&vts::stem_pipe_kernel<256, 128, 0, false>, lp);
+    allow(&vts::stem_pipe_kernel<256, 128, 1, false>, lp);
+    allow(&vts::stem_pipe_kernel<256, 128, 2, false>, lp);
+    allow(&vts::stem_pipe_kernel<256, 128, 0, true>, lp);
+    allow(&vts::stem_fused_kernel<0, false>, lf);
+    allow(&vts::stem_fused_kernel<1, false>, lf);
+    allow(&vts::stem_fused_kernel<2, false>, lf);
+    allow(&vts::stem_fused_kernel<0, true>, lf);
+    return e;
+}
+
 extern "C" {
 
 const char* vt_last_error(void) { return g_err.c_str(); }
@@ -560,20 +610,22 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
+
         (void)small_bytes;
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_pipe_kernel<256, 128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)vts::PipeGeo<256, 128>::LDS_BYTES);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vts::stem_fused_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, vts::FusedGeo::LDS_BYTES);
+            e = allow_stem_lds();
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(vth::Geo<16>::LDS_BYTES));
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));
         if (e != hipSuccess) rc = fail(VT_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (rc) {

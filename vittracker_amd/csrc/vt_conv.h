@@ -47,22 +47,18 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wimg, int
 //   base[i]  per-lane map offset of tap (0,0) for pixel tile i
 //   off(c)   per-lane map offset of this lane's quad of chunk c (tap + channel-quad part)
 // PIN: keep the next chunk's B reads ahead of this chunk's MFMAs (see below); costs registers, so opt-in.
-template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename OffFn>
-__device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT], const f4 (&a)[MAXC][NOT], int c0,
-                                         OffFn off, f4 (&acc)[NPT][NOT]) {
+// General form: at(c, i) = per-lane map offset of this lane's quad of chunk c for pixel tile i.
+template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename AtFn>
+__device__ __forceinline__ void mma_pass_at(const f4* in_map, const f4 (&a)[MAXC][NOT], int c0, AtFn at, f4 (&acc)[NPT][NOT]) {
     static_assert(N <= MAXC, "chunk count");
     f4 b[2][NPT];
-    {
-        const int o = off(c0);
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) b[0][i] = in_map[o + base[i]];
-    }
+    for (int i = 0; i < NPT; ++i) b[0][i] = in_map[at(c0, i)];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         if (k + 1 < N) {
-            const int o = off(c0 + k + 1);
 #pragma unroll
-            for (int i = 0; i < NPT; ++i) b[(k + 1) & 1][i] = in_map[o + base[i]];
+            for (int i = 0; i < NPT; ++i) b[(k + 1) & 1][i] = in_map[at(c0 + k + 1, i)];
             // keep these reads ahead of chunk k's MFMAs: left alone, the scheduler sinks them to just before
             // their first use and every chunk then starts with a full LDS round trip
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
@@ -82,6 +78,19 @@ __device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT
                     acc[i][ot] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k][ot][r], b[k & 1][i][r], acc[i][ot], 0, 0, 0);
 #endif
     }
+}
+
+// The common case: offset = base[i] (tap (0,0) of pixel tile i) + off(c) (tap + channel-quad part of chunk c).
+template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename OffFn>
+__device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT], const f4 (&a)[MAXC][NOT], int c0,
+                                         OffFn off, f4 (&acc)[NPT][NOT]) {
+    int oc = 0, ov = 0;      // off() of the last chunk asked for (at() is called for i = 0 .. NPT-1 of the same chunk in a row)
+    bool have = false;
+    auto at = [&](int c, int i) {
+        if (!have || c != oc) { ov = off(c); oc = c; have = true; }
+        return ov + base[i];
+    };
+    mma_pass_at<NOT, NPT, MAXC, N, PIN>(in_map, a, c0, at, acc);
 }
 
 // All NCH chunks of a layer in passes of MAXC (weights fetched per pass); NCH compile-time.

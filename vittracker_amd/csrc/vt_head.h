@@ -16,6 +16,8 @@
 // divmod(Q, CIN/4): 16 consecutive pixels per quarter-wave, conflict-free at F = 16
 // (tools/lds_conflicts.py).
 #pragma once
+#include <type_traits>
+
 #include "vt_common.h"
 #include "vt_conv.h"
 
@@ -44,18 +46,33 @@ static_assert(TOWER_STRIDE % 4 == 0 && O_W2 % 4 == 0 && O_W3 % 4 == 0 && O_W4 % 
 
 template <int F>
 struct Geo {
-    static constexpr int P = F + 2;                          // padded row pitch (pixels)
-    static constexpr int NPIX = ((P * P + 15) / 16) * 16;    // plane size (pixels)
+    // F = 16: a zero-bordered (F+2) x (F+2) grid; a quarter-wave reads 16 consecutive pixels of ONE row: conflict-free.
+    // F = 8: a quarter-wave reads 8 pixels of each of TWO rows; with a 10-pixel pitch the two 8-wide windows overlap in two bank
+    // groups (a ds_read_b128 lane covers 4 banks, so 16 float4 = one pass over the 64 banks): 43 % of the LDS-active cycles
+    // were conflict cycles.  NOHALO layout: the halo COLUMNS are not stored -- row pitch F = 8, so consecutive rows sit exactly
+    // half a bank cycle apart -- and a lane whose tap falls into the left / right halo reads a zero entry from the plane's zero
+    // tail instead, placed in the bank group the other 14 lanes leave free (left: 7 / 15, right: 0 / 8; + dy * 8 keeps that).
+    static constexpr bool NOHALO = F == 8;
+    static constexpr int P = NOHALO ? F : F + 2;                               // row pitch (pixels)
+    static constexpr int ROWS = F + 2;                                          // zero row above and below
+    static constexpr int NPIX = NOHALO ? ROWS * P + 32 : ((P * P + 15) / 16) * 16;   // plane size (pixels); NOHALO: 32 zero entries behind the rows
+    static constexpr int ZR = ROWS * P, ZL = ROWS * P + 7;                      // NOHALO: zero entries for the right / left halo (+ 8 dy)
+    static_assert(!NOHALO || (P == 8 && ZL + 2 * P < NPIX && NPIX % 16 == 0), "zero tail");
     static constexpr int NT = F * F / 16;                    // 16-pixel output tiles
     static constexpr int NPT = NT / 4;                       // tiles per wave (4 waves)
     static constexpr int QUADS = C / 4 + W1 / 4 + 4;         // in(12) + ping(8) + pong(4)
     static constexpr int LDS_BYTES = QUADS * NPIX * 16;
-    // padded pixel index of this lane's output pixel in tile t, minus one row and one column
-    // (= the address of tap (0,0))
-    __device__ static __forceinline__ int tap00(int t, int lane) {
+    // plane index of map pixel (y, x), 0 <= y, x < F
+    __host__ __device__ static constexpr int interior(int y, int x) { return NOHALO ? (y + 1) * P + x : (y + 1) * P + x + 1; }
+    // per-lane plane indices of the three taps dx = 0, 1, 2 in kernel row dy = 0 for this lane's output pixel of tile t
+    // (add dy * P for the other kernel rows)
+    __device__ static __forceinline__ void tap_cols(int t, int lane, int (&cb)[3]) {
         const int px = lane & 15;
-        if constexpr (F == 16) return t * P + px;
-        else return (2 * t + (px >> 3)) * P + (px & 7);
+        static_assert(NOHALO, "the zero-bordered layout adds dx to one base instead");
+        const int x = px & 7, m = (2 * t + (px >> 3)) * P + x;
+        cb[1] = m;
+        cb[0] = x > 0 ? m - 1 : ZL;
+        cb[2] = x < F - 1 ? m + 1 : ZR;
     }
 };
 
@@ -89,46 +106,68 @@ struct HeadConv {
                                         const float* __restrict__ bias, int wave, int lane) {
         const int q = lane >> 4;
         const int ot = SPLIT_OT ? (wave & 1) : 0, tfirst = SPLIT_OT ? (wave >> 1) : wave;
-        int base[NPT];
-#pragma unroll
-        for (int i = 0; i < NPT; ++i) base[i] = G::tap00(tfirst + TSTEP * i, lane);
         f4 acc[NPT][1];
         const f4 bv = ld4(bias + 16 * ot + 4 * q);
 #pragma unroll
         for (int i = 0; i < NPT; ++i) acc[i][0] = bv;
-        auto off = [&](int c) {
-            int tap, icq;
-            vtc::decode_quad<NQ>(4 * c + q, tap, icq);
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            return icq * G::NPIX + dy * G::P + dx;
-        };
         const float* __restrict__ wb = wbase(wimg, wave);
+        int centre[NPT];       // plane index of this lane's output pixel of tile i
+        auto passes = [&](auto pass) {
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            constexpr int LASTN = NCH - (NPASS - 1) * MAXC;
-            if (p + 1 < NPASS)
-                vtc::load_weights<1, MAXC, NCH>(wb, (p + 1) * MAXC, p + 2 < NPASS ? MAXC : LASTN, lane, a[(p + 1) & 1]);
-            if (p + 1 < NPASS) vtc::mma_pass<1, NPT, MAXC, MAXC, true>(in_map, base, a[p & 1], p * MAXC, off, acc);
-            else vtc::mma_pass<1, NPT, MAXC, LASTN, true>(in_map, base, a[p & 1], p * MAXC, off, acc);
+            for (int p = 0; p < NPASS; ++p) {
+                constexpr int LASTN = NCH - (NPASS - 1) * MAXC;
+                if (p + 1 < NPASS)
+                    vtc::load_weights<1, MAXC, NCH>(wb, (p + 1) * MAXC, p + 2 < NPASS ? MAXC : LASTN, lane, a[(p + 1) & 1]);
+                if (p + 1 < NPASS) pass(std::integral_constant<int, MAXC>{}, p);
+                else pass(std::integral_constant<int, LASTN>{}, p);
+            }
+        };
+        if constexpr (G::NOHALO) {
+            int cb[NPT][3];
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) { G::tap_cols(tfirst + TSTEP * i, lane, cb[i]); centre[i] = cb[i][1] + G::P; }
+            // map offset of this lane's quad of chunk c for pixel tile i.  With a multiple of 4 channel-quads per tap a chunk
+            // never straddles two taps, so the tap (and with it the column base) is a compile-time property of the unrolled chunk.
+            auto at = [&](int c, int i) {
+                int tap, icq;
+                if constexpr (NQ % 4 == 0) { tap = (4 * c) / NQ; icq = 4 * c - tap * NQ + q; }
+                else vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                return icq * G::NPIX + dy * G::P + (dx == 0 ? cb[i][0] : (dx == 1 ? cb[i][1] : cb[i][2]));
+            };
+            passes([&](auto n, int p) { vtc::mma_pass_at<1, NPT, MAXC, decltype(n)::value, true>(in_map, a[p & 1], p * MAXC, at, acc); });
+        } else {
+            int base[NPT];     // tap (0,0): one row up, one column left of the output pixel in the zero-bordered grid
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) { base[i] = (tfirst + TSTEP * i) * G::P + (lane & 15); centre[i] = base[i] + G::P + 1; }
+            auto off = [&](int c) {
+                int tap, icq;
+                vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                return icq * G::NPIX + dy * G::P + dx;
+            };
+            passes([&](auto n, int p) { vtc::mma_pass<1, NPT, MAXC, decltype(n)::value, true>(in_map, base, a[p & 1], p * MAXC, off, acc); });
         }
         if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
                 f4 v = acc[i][0];
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                out_map[(4 * ot + q) * G::NPIX + base[i] + G::P + 1] = v;
+                out_map[(4 * ot + q) * G::NPIX + centre[i]] = v;
             }
         }
     }
 };
 
 // grid (B, 3): tower 0 = ctr, 1 = offset, 2 = size.   feat: (B, F*F, 48) normalised search tokens.
-template <int F, int NW = 4>
+// DIAG: diagnostic build (VT_SKIP_HEAD); production instantiations compile `skip` out.
+template <int F, int NW = 4, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ hw,
                                                           float* __restrict__ score, float* __restrict__ size,
-                                                          float* __restrict__ offset, int skip) {   // skip: diagnostic
+                                                          float* __restrict__ offset, int skip_arg) {   // skip: diagnostic
     using G = Geo<F>;
+    const int skip = DIAG ? skip_arg : 0;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     f4* in_map = reinterpret_cast<f4*>(sm);            // 12 quads
     f4* m1 = in_map + (C / 4) * G::NPIX;               // 8 quads
@@ -150,8 +189,7 @@ __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __res
     if (!(skip & 2))
     for (int i = threadIdx.x; i < F * F * (C / 4); i += NW * 64) {
         const int icq = i / (F * F), pix = i % (F * F);
-        in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] =
-            ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
+        in_map[icq * G::NPIX + G::interior(pix / F, pix % F)] = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
     }
     __syncthreads();
     c2.prefetch(tw + O_W2, wave, lane);        // each layer's first burst is requested a layer early
@@ -167,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __res
     __syncthreads();
     // 1x1 conv + activation (head.py:187,194,200-201)
     for (int pix = threadIdx.x; pix < F * F; pix += NW * 64) {
-        const f4 v = m2[(pix / F + 1) * G::P + (pix % F) + 1];
+        const f4 v = m2[G::interior(pix / F, pix % F)];
         const int nout = (t == 0) ? 1 : 2;
         for (int o = 0; o < nout; ++o) {
             const f4 w5 = ld4(tw + O_W5 + 4 * o);
@@ -246,13 +284,14 @@ struct FusedHeadGeo {
     static constexpr int LDS_BYTES = ((C / 4) * G::NPIX + 3 * TOWER_F4) * 16 + OUT_FLOATS * 4;
 };
 
-template <int F>
+template <int F, bool DIAG = false>
 __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
                                                          const float* __restrict__ window, float* __restrict__ score,
                                                          float* __restrict__ size, float* __restrict__ offset,
                                                          float* __restrict__ pred, float* __restrict__ hann,
-                                                         float* __restrict__ conf, int skip) {   // skip: diagnostic
+                                                         float* __restrict__ conf, int skip_arg) {   // skip: diagnostic
     using G = Geo<F>;
+    const int skip = DIAG ? skip_arg : 0;
     using FG = FusedHeadGeo<F>;
     static_assert(F * F == 64, "the in-kernel decode assumes one map pixel per lane of a wave");
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -278,7 +317,7 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
     if (!(skip & 2))
     for (int i = threadIdx.x; i < F * F * (C / 4); i += 768) {
         const int icq = i / (F * F), pix = i % (F * F);
-        in_map[icq * G::NPIX + (pix / F + 1) * G::P + (pix % F) + 1] = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
+        in_map[icq * G::NPIX + G::interior(pix / F, pix % F)] = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
     }
     __syncthreads();
     c2.prefetch(tw + O_W2, wv, lane);
@@ -295,7 +334,7 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
     // 1x1 conv + activation (head.py:187,194,200-201) -> global maps and the LDS copy for the decode
     if (tid < F * F) {
         const int pix = tid;
-        const f4 v = m2[(pix / F + 1) * G::P + (pix % F) + 1];
+        const f4 v = m2[G::interior(pix / F, pix % F)];
         const int nout = (t == 0) ? 1 : 2;
         for (int o = 0; o < nout; ++o) {
             const f4 w5 = ld4(tw + O_W5 + 4 * o);

@@ -384,10 +384,13 @@ __host__ __device__ constexpr int stem_b_lds_bytes(int S2, int r4) {
 }
 
 // w3img: [2][7][64][4] (24 -> 32 padded output channels), b3: 32; w4img: [3][14][64][4], b4: 48.
+// DIAG: the diagnostic build (VT_SKIP_STEM_B); the production instantiation compiles `skip` out.
+template <bool DIAG>
 __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const float* __restrict__ w3img,
                                                      const float* __restrict__ b3, const float* __restrict__ w4img,
                                                      const float* __restrict__ b4, float* __restrict__ tokens, int L,
-                                                     int skip) {   // skip: phase-timing diagnostic, 0 in production
+                                                     int skip_arg) {   // skip: phase-timing diagnostic, 0 in production
+    const int skip = DIAG ? skip_arg : 0;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int per = cx.bands + cz.bands;
     const int b = blockIdx.x / per;

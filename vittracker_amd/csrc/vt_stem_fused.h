@@ -54,21 +54,34 @@ struct FusedGeo {                       // TX = 128, TZ = 64
     static_assert((2 * R2X) * (TX / 4) == 512 && (2 * R2Z) * (TZ / 4) == 512, "one pixel pair per thread of a group");
 };
 
-struct BandF {            // one band of one crop (all wave-uniform)
-    const float* in;      // this frame's crop (3, T, T)
-    int lgT, HALF, lgHALF, PITCH, npix1, p0, R2, lgW2, m2_off, pitch2, half2, npix2;
-    bool halo;            // top halo row comes from the other group's ring (else: image top, zeros)
+// One band of one crop.  Everything but the crop pointer is a compile-time constant of (crop, band index): left as run-time
+// fields (selected per group and step) they cost ~100 VALU instructions of address set-up per layer-2 call.
+template <bool IS_Z, int XB>
+struct BandF {
+    using G = FusedGeo;
+    static constexpr int T = IS_Z ? G::TZ : G::TX;
+    static constexpr int lgT = IS_Z ? 6 : 7, HALF = T >> 2, lgHALF = lgT - 2, PITCH = (T >> 1) + 1;
+    static constexpr int npix1 = IS_Z ? G::NPIX1Z : G::NPIX1X;
+    static constexpr int R2 = IS_Z ? G::R2Z : G::R2X, p0 = IS_Z ? 0 : XB * G::R2X, lgW2 = lgT - 2;
+    static constexpr int m2_off = IS_Z ? 3 * G::NPIX2X : 0, pitch2 = (T >> 2) + 1, half2 = T >> 3;
+    static constexpr int npix2 = IS_Z ? G::NPIX2Z : G::NPIX2X;
+    static constexpr bool halo = !IS_Z && XB > 0;      // top halo row comes from the other group's ring (else: image top, zeros)
+    const float* in;                                    // this frame's crop (3, T, T)
 };
 
+// ZMODE 0: both crops; 1: search crop only (the template's token rows are cached in `tokens`); 2: template only.
+// DIAG: the diagnostic build (VT_SKIP_* / VT_DBG_STAMPS); production instantiations compile `skip` and the stamps out -- as
+// run-time conditions they put every band's prefetched registers through a copy at each conditional call.
+template <int ZMODE, bool DIAG>
 __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin,                       // (B,3,64,64), (B,3,128,128)
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
     const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
-    const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip,
-    unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
-    int zmode) {   // 0: both crops; 1: search crop only (the template's token rows are cached in `tokens`); 2: template only
+    const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip_arg,
+    unsigned long long* __restrict__ stamps) {     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
     using G = FusedGeo;
-    const bool do_z = zmode != 1, do_x = zmode != 2;
+    constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
+    const int skip = DIAG ? skip_arg : 0;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     f4* const lds = reinterpret_cast<f4*>(lds_f);
     f4* const ring0 = lds;                                   // group A's layer-1 ring
@@ -89,28 +102,20 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     f4* const ring = ring0 + grp * G::RING;
     const f4* const other_ring = ring0 + (1 - grp) * G::RING;
 
-    // band `s` of this wave's group: A = {z, x1, x3}, B = {x0, x2}
-    auto band = [&](int s) {
-        BandF J;
-        const bool is_z = grp == 0 && s == 0;
-        const int T = is_z ? G::TZ : G::TX;
-        const int xb = grp == 0 ? 2 * s - 1 : 2 * s;        // search band index (unused for z)
-        J.in = is_z ? zin + (size_t)b * 3 * G::TZ * G::TZ : xin + (size_t)b * 3 * G::TX * G::TX;
-        J.lgT = is_z ? 6 : 7; J.HALF = T >> 2; J.lgHALF = J.lgT - 2; J.PITCH = (T >> 1) + 1;
-        J.npix1 = is_z ? G::NPIX1Z : G::NPIX1X;
-        J.R2 = is_z ? G::R2Z : G::R2X; J.p0 = is_z ? 0 : xb * G::R2X; J.lgW2 = J.lgT - 2;
-        J.m2_off = is_z ? M2Z_OFF : 0; J.pitch2 = (T >> 2) + 1; J.half2 = T >> 3;
-        J.npix2 = is_z ? G::NPIX2Z : G::NPIX2X;
-        J.halo = !is_z && xb > 0;
-        return J;
-    };
-    const int nbands = grp == 0 ? 3 : 2;
+    // bands of this frame: group A = {z, x1, x3}, group B = {x0, x2}
+    const float* const zin_b = zin + (size_t)b * 3 * G::TZ * G::TZ;
+    const float* const xin_b = xin + (size_t)b * 3 * G::TX * G::TX;
+    const BandF<true, 0> bz{zin_b};
+    const BandF<false, 0> bx0{xin_b};
+    const BandF<false, 1> bx1{xin_b};
+    const BandF<false, 2> bx2{xin_b};
+    const BandF<false, 3> bx3{xin_b};
 
     // ---- layer 1 pieces ------------------------------------------------------------------------------
     const int pair = gw * 64 + lane;                         // this thread's pixel pair of a band (0..511)
     // Raw loads only: nothing here may depend on the loaded data, so the requests stay in flight across
     // the layer-2 work and the barrier that follow (the top-of-image zeroing is applied in layer1).
-    auto fetch = [&](const BandF& J, f4 (&v)[3][3]) {
+    auto fetch = [&](const auto& J, f4 (&v)[3][3]) {
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const int p1 = 2 * J.p0 - 1 + lr;                    // layer-1 row (>= 0)
 #pragma unroll
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off);
         }
     };
-    auto layer1 = [&](const BandF& J, const f4 (&v)[3][3]) {
+    auto layer1 = [&](const auto& J, const f4 (&v)[3][3]) {
         // layer 1 is the long pole of an interval (VALU-bound); without this the issue arbiter favours the
         // older group whatever it is doing, and the younger group's layer 1 takes three times as long
         __builtin_amdgcn_s_setprio(3);
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     };
 
     // ---- layer 2: this group's ring -> the frame's layer-2 map ------------------------------------------
-    auto layer2 = [&](const BandF& J) {
+    auto layer2 = [&](const auto& J) {
         f4 w2a[5][1];
 #pragma unroll
         for (int c = 0; c < 5; ++c) w2a[c][0] = cw2[c * 64 + lane];
@@ -199,17 +204,19 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
 
     int nstamp = 0;
     auto stamp = [&]() {
-        if (stamps != nullptr) {
-            unsigned long long tt;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
-            if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
-            ++nstamp;
+        if constexpr (DIAG) {
+            if (stamps != nullptr) {
+                unsigned long long tt;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+                if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
+                ++nstamp;
+            }
         }
     };
     stamp();
     // ---- start: the first bands' inputs are requested before the LDS is cleared ---------------------------
     f4 v[3][3];
-    if (grp == 0 ? do_z : do_x) fetch(band(0), v);
+    if (grp == 0) { if (do_z) fetch(bz, v); } else if (do_x) fetch(bx0, v);
     {   // constants -> LDS; zero only what is read without ever being written: the top rows of the rings,
         // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
         const int t = threadIdx.x;
@@ -250,22 +257,22 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         const bool l2 = !(skip & 2);
         // zmode: a crop that is not wanted keeps its barriers and drops its work (all conditions are wave-uniform)
         if (grp == 0) {
-            if (do_z) layer1(band(0), v);           stamp(); __syncthreads(); stamp();   // 0: L1(z)
-            if (do_x) fetch(band(1), v);
-            if (l2 && do_z) layer2(band(0));        stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
-            if (do_x) layer1(band(1), v);           stamp(); __syncthreads(); stamp();   // 2: L1(x1)
-            if (do_x) fetch(band(2), v);
-            if (l2 && do_x) layer2(band(1));        stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
-            if (do_x) layer1(band(2), v);           stamp(); __syncthreads(); stamp();   // 4: L1(x3)
+            if (do_z) layer1(bz, v);                stamp(); __syncthreads(); stamp();   // 0: L1(z)
+            if (do_x) fetch(bx1, v);
+            if (l2 && do_z) layer2(bz);             stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
+            if (do_x) layer1(bx1, v);               stamp(); __syncthreads(); stamp();   // 2: L1(x1)
+            if (do_x) fetch(bx3, v);
+            if (l2 && do_x) layer2(bx1);            stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
+            if (do_x) layer1(bx3, v);               stamp(); __syncthreads(); stamp();   // 4: L1(x3)
             load_w3();
-            if (l2 && do_x) layer2(band(2));        stamp(); __syncthreads(); stamp();   // 5: L2(x3)
+            if (l2 && do_x) layer2(bx3);            stamp(); __syncthreads(); stamp();   // 5: L2(x3)
         } else {
             stamp(); __syncthreads(); stamp();   // 0: (x0 requested at kernel start)
-            if (do_x) layer1(band(0), v);           stamp(); __syncthreads(); stamp();   // 1: L1(x0)
-            if (do_x) fetch(band(1), v);
-            if (l2 && do_x) layer2(band(0));        stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
-            if (do_x) layer1(band(1), v);           stamp(); __syncthreads(); stamp();   // 3: L1(x2)
-            if (l2 && do_x) layer2(band(1));        stamp(); __syncthreads(); stamp();   // 4: L2(x2)
+            if (do_x) layer1(bx0, v);               stamp(); __syncthreads(); stamp();   // 1: L1(x0)
+            if (do_x) fetch(bx2, v);
+            if (l2 && do_x) layer2(bx0);            stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
+            if (do_x) layer1(bx2, v);               stamp(); __syncthreads(); stamp();   // 3: L1(x2)
+            if (l2 && do_x) layer2(bx2);            stamp(); __syncthreads(); stamp();   // 4: L2(x2)
             load_w3();                              __syncthreads();   // 5
         }
     }
@@ -365,14 +372,15 @@ struct PipeGeo {
     static_assert((R2X * (TX / 4)) == 256 && (R2Z * (TZ / 4)) == 256, "16 layer-2 tiles per band");
 };
 
-template <int TX, int TZ>
+template <int TX, int TZ, int ZMODE, bool DIAG>
 __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
-    const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip,
-    unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
-    int zmode) {   // 0: both crops; 1: search bands only (template cached downstream); 2: template bands only
+    const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip_arg,
+    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    // ZMODE 0: both crops; 1: search bands only (template cached downstream); 2: template bands only.  DIAG: see stem_fused_kernel.
     using G = PipeGeo<TX, TZ>;
-    const int s_lo = zmode == 1 ? G::NBZ / 2 : 0, s_hi = zmode == 2 ? G::NBZ / 2 : G::NB / 2;   // band pairs [s_lo, s_hi)
+    const int skip = DIAG ? skip_arg : 0;
+    constexpr int s_lo = ZMODE == 1 ? G::NBZ / 2 : 0, s_hi = ZMODE == 2 ? G::NBZ / 2 : G::NB / 2;   // band pairs [s_lo, s_hi)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     f4* const ring0 = reinterpret_cast<f4*>(lds_f);
     f4* const cw2 = ring0 + 2 * G::RING;
@@ -488,11 +496,13 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
 
     int nstamp = 0;
     auto stamp = [&]() {
-        if (stamps != nullptr && nstamp < 32) {
-            unsigned long long tt;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
-            if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
-            ++nstamp;
+        if constexpr (DIAG) {
+            if (stamps != nullptr && nstamp < 32) {
+                unsigned long long tt;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+                if (lane == 0) stamps[((size_t)b * 16 + wave) * 32 + nstamp] = tt;
+                ++nstamp;
+            }
         }
     };
     stamp();
