@@ -140,6 +140,13 @@ int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resi
 /* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,
                      const vt_outputs* out, vt_graph** g);
+/* nsteps consecutive frames in ONE graph: step i is vt_forward(z_dev[i], x_dev[i], out[i]) (z_dev, or any z_dev[i], may be NULL
+ * after vt_set_template; out may be NULL).  Steps run in order, so they may share buffers.  For callers that have the next
+ * crops on the device already -- offline evaluation (lib/test/evaluation/running.py:56-102 reads whole sequences), or frames
+ * pipelined a few deep: the runtime leaves ~7 us between two graph launches, 4 steps per graph recover ~5 % of a G128 / B=256
+ * step (tools/graph_steps.py). */
+int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_dev, const float* const* x_dev, int32_t B,
+                           const vt_outputs* out, vt_graph** g);
 int vt_graph_launch(vt_graph* g, void* stream);
 void vt_graph_destroy(vt_graph* g);
 

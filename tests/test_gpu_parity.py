@@ -217,3 +217,41 @@ def test_kernel_form_follows_the_batch_size_within_fp32_noise(geom):
         part = m.forward(zd[i0:i0 + n].contiguous(), xd[i0:i0 + n].contiguous())
         for k in ("score_map", "size_map", "offset_map"):
             np.testing.assert_allclose(getattr(part, k).cpu().numpy(), getattr(big, k)[i0:i0 + n].cpu().numpy(), atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_multi_step_graph_equals_eager_steps(geom):
+    """vt_graph_capture_steps: n consecutive frames in one graph == n eager forwards, bit for bit, with their own inputs and
+    outputs; also with the cached template (z = None), and with steps sharing one output set (the last step wins)."""
+    import torch
+    from vittracker_amd import native, synth
+    tz, tx = GEOMS[geom]
+    B, n = 3, 3
+    m = native.Model(tz, tx, max_batch=B)
+    m.load_state_dict(synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2))
+    zs, xs = [], []
+    for i in range(n):
+        z, x = synth.synth_inputs(10 + i, B, tz, tx)
+        zs.append(torch.from_numpy(z).cuda()); xs.append(torch.from_numpy(x).cuda())
+    eager = [m.forward(z, x) for z, x in zip(zs, xs)]
+    g, outs = m.capture_steps(zs, xs)
+    g.launch(); g.launch()
+    torch.cuda.synchronize()
+    for e, o in zip(eager, outs):
+        for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+            assert torch.equal(getattr(e, k), getattr(o, k)), k
+    # cached template + one shared output set
+    m.set_template(zs[0])
+    shared = native.Outputs(B, m.feat_sz, "cuda")
+    g2, _ = m.capture_steps(None, xs, [shared] * n)
+    g2.launch()
+    torch.cuda.synchronize()
+    want = m.forward(zs[0], xs[-1])
+    assert torch.equal(shared.score_map, want.score_map) and torch.equal(shared.hann_boxes, want.hann_boxes)
+    with pytest.raises(native.VtError, match="same length"):
+        m.capture_steps(zs[:2], xs)
+    with pytest.raises(native.VtError):
+        m.capture_steps(zs, [xs[0], xs[1], xs[2][:2]])
+    m.close()
+    with pytest.raises(native.VtError, match="closed or re-sized"):
+        g.launch()

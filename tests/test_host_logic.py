@@ -223,14 +223,15 @@ def test_bench_self_launches_two_ranks_plumbing_only():
     child, relays ONE JSON line and exits with the child's code (here on gloo with compute skipped)."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "3",
-                        "--warmup", "1", "--batch", "8"], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "7",
+                        "--steps-per-graph", "3", "--warmup", "1", "--batch", "8"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and len(j["per_rank_frames_per_s"]) == 2
     assert "gather_exposed_us_per_step" in j and j["scaling"] == "weak"
+    assert j["steps"] == 7 and j["config"]["steps_per_graph"] == 3      # 2 launch units of 3 steps + 1 single step
 
 
 def test_bench_refuses_diagnostic_switches():

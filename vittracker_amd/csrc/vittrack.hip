@@ -877,29 +877,31 @@ static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0,
     return run_head(m, feat, nb, st, out, f0);
 }
 
-int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, const vt_outputs* out,
-                     vt_graph** g) {
+int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_dev, const float* const* x_dev, int32_t B,
+                           const vt_outputs* out, vt_graph** g) {
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!g) return fail(VT_ERR_ARG, "null graph out");
-    // The batch is captured as NCH independent chains over frame slices (fork / join with events):
+    if (nsteps < 1 || nsteps > 64 || !x_dev) return fail(VT_ERR_ARG, "vt_graph_capture_steps: 1..64 steps, x_dev must not be null");
+    // One step may be captured as NCH independent chains over frame slices (fork / join with events):
     // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
     // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
     int nch = m->graph_chains;   // default 1
-    nch = (m->vb || !z_dev) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
+    nch = (m->vb || nsteps > 1 || !z_dev || !z_dev[0]) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
     rc = VT_OK;
     if (nch == 1) {
-        rc = vt_forward(m, z_dev, x_dev, B, m->cap_stream, out);
+        for (int i = 0; i < nsteps && !rc; ++i)
+            rc = vt_forward(m, z_dev ? z_dev[i] : nullptr, x_dev[i], B, m->cap_stream, out ? &out[i] : nullptr);
     } else {
         if (hipEventRecord(m->fork_ev, m->cap_stream) != hipSuccess) rc = fail(VT_ERR_HIP, "hipEventRecord(fork)");
         for (int c = 1; c < nch && !rc; ++c)
             if (hipStreamWaitEvent(m->side_stream[c - 1], m->fork_ev, 0) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamWaitEvent(fork)");
         for (int c = 0; c < nch && !rc; ++c) {
             const size_t f0 = (size_t)B * c / nch, f1 = (size_t)B * (c + 1) / nch;
-            rc = forward_slice(m, z_dev, x_dev, f0, (int)(f1 - f0), c == 0 ? m->cap_stream : m->side_stream[c - 1], out);
+            rc = forward_slice(m, z_dev[0], x_dev[0], f0, (int)(f1 - f0), c == 0 ? m->cap_stream : m->side_stream[c - 1], out);
         }
         for (int c = 1; c < nch; ++c) {   // always join, even after an error, so the capture can end
             (void)hipEventRecord(m->join_ev[c - 1], m->side_stream[c - 1]);
@@ -913,6 +915,10 @@ int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_
     if (e != hipSuccess) { (void)hipGraphDestroy(vg->graph); delete vg; return fail(VT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     *g = vg;
     return VT_OK;
+}
+
+int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, const vt_outputs* out, vt_graph** g) {
+    return vt_graph_capture_steps(m, 1, &z_dev, &x_dev, B, out, g);
 }
 
 int vt_graph_launch(vt_graph* g, void* stream) {

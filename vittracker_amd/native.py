@@ -23,7 +23,7 @@ SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
-    "vt_set_template",
+    "vt_set_template", "vt_graph_capture_steps",
 ]
 
 
@@ -80,6 +80,7 @@ def lib(precision: str = "f32"):
     L.vt_head.argtypes = [vp, vp, i32, vp, C.POINTER(VtOutputs)]
     L.vt_cal_bbox.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
     L.vt_graph_capture.argtypes = [vp, vp, vp, i32, C.POINTER(VtOutputs), C.POINTER(vp)]
+    L.vt_graph_capture_steps.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(VtOutputs), C.POINTER(vp)]
     L.vt_graph_launch.argtypes = [vp, vp]
     L.vt_graph_destroy.argtypes = [vp]
     L.vt_graph_destroy.restype = None
@@ -295,6 +296,34 @@ class Model:
         gr = Graph(g, (z, x, out), self)
         self._graphs.add(gr)
         return gr, out
+
+    def capture_steps(self, zs, xs, outs=None) -> tuple[Graph, list]:
+        """``len(xs)`` consecutive steps in ONE graph: step i is ``forward(zs[i], xs[i], outs[i])``.  ``zs`` may be None (cached
+        template) or hold None entries; steps run in order and may share tensors.  One launch then advances ``len(xs)`` frames --
+        the gap the runtime leaves between two graph launches (~7 us) is paid once per graph instead of once per step."""
+        n = len(xs)
+        if n < 1:
+            raise VtError("capture_steps needs at least one step")
+        zs = list(zs) if zs is not None else [None] * n
+        if len(zs) != n or (outs is not None and len(outs) != n):
+            raise VtError("capture_steps: zs, xs and outs must have the same length")
+        B = None
+        for z, x in zip(zs, xs):
+            b = self._check_crops(z, x) if z is not None else self._check_x_only(x)
+            if B is not None and b != B:
+                raise VtError("capture_steps: every step must have the same batch size")
+            B = b
+        outs = list(outs) if outs is not None else [Outputs(B, self.feat_sz, xs[0].device) for _ in range(n)]
+        for o in outs:
+            self._check_out(o, B)
+        zp = (C.c_void_p * n)(*[_ptr(z) for z in zs])
+        xp = (C.c_void_p * n)(*[_ptr(x) for x in xs])
+        sts = (VtOutputs * n)(*[o.struct() for o in outs])
+        g = C.c_void_p()
+        _check(self._L.vt_graph_capture_steps(self._h, n, zp, xp, B, sts, C.byref(g)), "vt_graph_capture_steps", self._L)
+        gr = Graph(g, (zs, list(xs), outs), self)
+        self._graphs.add(gr)
+        return gr, outs
 
     # ---- stages
     def stem(self, z, x, stream=None):
