@@ -139,3 +139,48 @@ def test_batched_tracker_equals_independent_plugin_trackers():
     for f in range(1, n):
         last = bt2.track(vids[f], sync=False)
     np.testing.assert_array_equal(last["target_bbox"].cpu().numpy(), out["target_bbox"].numpy())
+
+
+def test_track_chunk_equals_frame_by_frame_tracking():
+    """n frames per graph launch (crop -> forward -> state update, n times, in one captured graph) give, frame by frame, exactly
+    what track() gives -- from host frames and from a device buffer, and again after re-initialising (the captured graphs read
+    the template cache, which initialize() refreshes in place)."""
+    import torch
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.native import VtError
+    from vittracker_amd.parameter import vit_dist as P
+    os.environ["VITTRACK_PRJ_DIR"] = REPO
+    p = P.parameters("vit_48_h32_noKD")
+    p.allow_synthetic_weights = True
+    B, n, H, W = 3, 7, 180, 240
+    rs = np.random.RandomState(5)
+    vids = rs.randint(0, 256, (n, B, H, W, 3)).astype(np.uint8)
+    boxes0 = [[50 + 12 * b, 40 + 6 * b, 44, 30 + 3 * b] for b in range(B)]
+    ref = BatchedVitTracker(p, B)
+    with pytest.raises(VtError, match="before initialize"):
+        ref.track_chunk(vids[1:3])
+    ref.initialize(vids[0], boxes0)
+    want_b, want_c = [], []
+    for f in range(1, n):
+        o = ref.track(vids[f])
+        want_b.append(o["target_bbox"].numpy().copy()); want_c.append(o["confidence"].numpy().copy())
+    want_b, want_c = np.stack(want_b), np.stack(want_c)
+
+    bt = BatchedVitTracker(p, B)
+    bt.initialize(vids[0], boxes0)
+    o1 = bt.track_chunk(vids[1:4])                       # host frames, 3 per launch
+    dev = torch.from_numpy(vids[4:7]).cuda()
+    o2 = bt.track_chunk(dev)                             # device frames, used in place
+    np.testing.assert_array_equal(np.concatenate([o1["target_bbox"].numpy(), o2["target_bbox"].numpy()]), want_b)
+    np.testing.assert_array_equal(np.concatenate([o1["confidence"].numpy(), o2["confidence"].numpy()]), want_c)
+    assert bt.frame_id == 6
+    # a second pass over the same buffers after re-initialising on another template: graphs are reused, results follow the new template
+    boxes1 = [[80 + 5 * b, 60, 36, 36] for b in range(B)]
+    ref.initialize(vids[2], boxes1)
+    bt.initialize(vids[2], boxes1)
+    w = np.stack([ref.track(vids[f])["target_bbox"].numpy().copy() for f in range(4, 7)])
+    got = bt.track_chunk(dev)["target_bbox"].numpy()
+    np.testing.assert_array_equal(got, w)
+    assert len(bt._chunk_graphs) == 2
+    with pytest.raises(ValueError):
+        bt.track_chunk(vids[1:3, :2])

@@ -54,6 +54,18 @@ def main():
     dt = time.time() - t0
     print(f"frames already on the device: {B * a.frames / dt:.0f} frames/s, {dt / a.frames * 1e3:.3f} ms per step")
     print("last boxes[0]:", out["target_bbox"][0].tolist())
+    for n in (2, 4):      # n frames per graph launch (crop -> forward -> state update, n times, one graph)
+        chunk = dev[[i & 1 for i in range(n)]].contiguous()
+        for _ in range(3):       # the first replays of a fresh graph include its upload
+            bt.track_chunk(chunk, sync=False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for f in range(a.frames // n):
+            out = bt.track_chunk(chunk, sync=False)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"track_chunk, {n} frames per launch, frames on the device: {B * (a.frames // n) * n / dt:.0f} frames/s, "
+              f"{dt / ((a.frames // n) * n) * 1e3:.3f} ms per frame")
 
 
 if __name__ == "__main__":

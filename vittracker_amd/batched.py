@@ -56,10 +56,16 @@ class BatchedVitTracker:
         self.x = torch.zeros(batch, 3, params.search_size, params.search_size, device=dev)
         self.states = torch.zeros(batch, 4, dtype=torch.float64, device=dev)
         self.rf = torch.zeros(batch, dtype=torch.float64, device=dev)
-        self.graph, self.out = self.nat.capture(self.z, self.x)
+        from .native import Outputs
+        self.out = Outputs(batch, F, dev)
+        self.graph = None            # captured at the first initialize(): the forward reads the cached template (z = None)
+        self._chunk_graphs = {}      # (frame buffer address, n, H, W) -> whole-step graph of n frames (track_chunk)
+        self._chunk_buf = None
+        self._chunk_pinned = None
         self.frames = None
         self._pinned = None
         self._h2d_done = None
+        self._chunk_h2d = None
         self._slot = 0
         self.hw = None
         self.frame_id = 0
@@ -112,11 +118,19 @@ class BatchedVitTracker:
         self.states.copy_(torch.as_tensor(boxes))
         self.nat.crop(fr, self.states, self.params.template_factor, self.params.template_size, self.mean, self.std,
                       out=self.z, resize_factor=self.rf)
+        # The template never changes after this (lib/test/tracker/vit_dist.py:57-60): its patch embedding and block 0's
+        # LayerNorm-1 + qkv rows are computed once here (vt_set_template, bit-identical to recomputing them every frame);
+        # graphs captured with z = None read that cache, so they stay valid across re-initialisation.
+        self.nat.set_template(self.z)
+        if self.graph is None:
+            self.graph, _ = self.nat.capture(None, self.x, self.out)
         self.frame_id = 0
 
     def track(self, frames, sync: bool = True):
         """Advance every sequence by one frame.  Returns {'target_bbox': (B,4) float64, 'confidence': (B,)}
         as CPU tensors when sync=True, else the device tensors (valid until the next call)."""
+        if self.graph is None:
+            raise VtError("track before initialize")
         fr = self._upload(frames)
         H, W = self.hw
         self.frame_id += 1
@@ -127,3 +141,71 @@ class BatchedVitTracker:
         if sync:
             return {"target_bbox": self.states.cpu(), "confidence": self.out.conf.cpu()}
         return {"target_bbox": self.states, "confidence": self.out.conf}
+
+    # ---- n frames per launch ------------------------------------------------------------------------------------
+    def _chunk_graph(self, buf):
+        """The whole tracker step -- crop -> forward -> map back / clip / state update -> record -- for the n frames of `buf`
+        (n,B,H,W,3), captured once per frame buffer into ONE graph: no host work and one launch gap per n frames."""
+        import torch
+        n, _, H, W, _ = buf.shape
+        key = (buf.data_ptr(), n, H, W)
+        hit = self._chunk_graphs.get(key)
+        if hit is not None:
+            return hit
+        if len(self._chunk_graphs) >= 4:                      # a caller cycling through many buffers: keep the table small
+            self._chunk_graphs.pop(next(iter(self._chunk_graphs)))
+        boxes = torch.empty(n, self.B, 4, dtype=torch.float64, device="cuda")
+        conf = torch.empty(n, self.B, device="cuda")
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=side):
+            cs = torch.cuda.current_stream()
+            for i in range(n):
+                self.nat.crop(buf[i], self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
+                              out=self.x, resize_factor=self.rf, stream=cs)
+                self.nat.forward(None, self.x, out=self.out, stream=cs)
+                self.nat.update_state(self.out.hann_boxes, self.rf, self.states, self.params.search_size, H, W, margin=10, stream=cs)
+                boxes[i].copy_(self.states)
+                conf[i].copy_(self.out.conf)
+        torch.cuda.current_stream().wait_stream(side)
+        self._chunk_graphs[key] = (g, boxes, conf, buf)       # buf: the graph's kernels read it, keep it alive
+        return self._chunk_graphs[key]
+
+    def track_chunk(self, frames, sync: bool = True):
+        """Advance every sequence by n = len(frames) frames with ONE graph launch: frames (n,B,H,W,3) uint8, a CUDA tensor (used in
+        place: the graph is captured on its address and reused whenever the same buffer comes back) or host data (uploaded into
+        an internal n-deep device buffer).  For callers that have the next frames at hand -- offline evaluation reads whole
+        sequences (lib/test/evaluation/running.py:56-102).  Frame by frame the same kernels run in the same order as in
+        track(): results are bit-identical.  Returns {'target_bbox': (n,B,4) float64, 'confidence': (n,B)}."""
+        import torch
+        if self.graph is None:
+            raise VtError("track_chunk before initialize")
+        if isinstance(frames, torch.Tensor) and frames.is_cuda:
+            buf = frames
+            if buf.dtype != torch.uint8 or buf.dim() != 5 or buf.shape[1] != self.B or buf.shape[4] != 3 or not buf.is_contiguous():
+                raise ValueError(f"frames must be a contiguous (n, B={self.B}, H, W, 3) uint8 tensor")
+        else:
+            a = np.ascontiguousarray(np.stack(frames) if not isinstance(frames, np.ndarray) else frames)
+            if a.dtype != np.uint8 or a.ndim != 5 or a.shape[1] != self.B or a.shape[4] != 3:
+                raise ValueError(f"frames must be (n, B={self.B}, H, W, 3) uint8")
+            if self._chunk_buf is None or tuple(self._chunk_buf.shape) != a.shape:
+                torch.cuda.current_stream().synchronize()
+                self._chunk_buf = torch.empty(a.shape, dtype=torch.uint8, device="cuda")
+                self._chunk_pinned = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
+                self._chunk_h2d = None
+            if self._chunk_h2d is not None:
+                self._chunk_h2d.synchronize()                 # the copy that last read the staging buffer
+            self._chunk_pinned.copy_(torch.from_numpy(a))
+            self._chunk_buf.copy_(self._chunk_pinned, non_blocking=True)
+            self._chunk_h2d = torch.cuda.Event()
+            self._chunk_h2d.record()
+            buf = self._chunk_buf
+        n = int(buf.shape[0])
+        self.hw = (int(buf.shape[2]), int(buf.shape[3]))
+        g, boxes, conf, _ = self._chunk_graph(buf)
+        g.replay()
+        self.frame_id += n
+        if sync:
+            return {"target_bbox": boxes.cpu(), "confidence": conf.cpu()}
+        return {"target_bbox": boxes, "confidence": conf}
