@@ -40,6 +40,10 @@ def test_sequential_and_batched_runs_write_identical_box_files(tmp_path, monkeyp
         assert a == b and len(a.splitlines()) == len(s), s.name
         tl = open(os.path.join(tb.results_dir, s.name + "_time.txt")).read().splitlines()
         assert len(tl) == len(s) and all(float(v) > 0 for v in tl)
+    tc = _tracker(tmp_path / "chunk", monkeypatch)
+    run_dataset_batched(ds, tc, batch=4, frames_per_launch=3)     # 3 frames per graph launch: the same files again
+    for s in ds:
+        assert open(os.path.join(tc.results_dir, s.name + ".txt")).read() == open(os.path.join(tb.results_dir, s.name + ".txt")).read()
     # the target really is tracked on these textures? no: weights are synthetic -- only consistency is asserted
 
 

@@ -127,6 +127,17 @@ class _FakeBatched:
         self.state[:, 0] += 2.0
         return {"target_bbox": torch.from_numpy(self.state.copy()), "confidence": torch.zeros(self.B)}
 
+    def track_chunk(self, frames, sync=True):
+        import torch
+        assert frames.ndim == 5 and frames.shape[1] == self.B
+        self.chunks = getattr(self, "chunks", 0) + 1
+        rows = []
+        for _ in range(frames.shape[0]):
+            self.steps += 1
+            self.state[:, 0] += 2.0
+            rows.append(self.state.copy())
+        return {"target_bbox": torch.from_numpy(np.stack(rows)), "confidence": torch.zeros(frames.shape[0], self.B)}
+
 
 def test_batched_runner_ragged_lengths_and_rank_sharding(monkeypatch, tmp_path):
     from vittracker_amd.evaluation import Tracker, get_dataset
@@ -147,6 +158,25 @@ def test_batched_runner_ragged_lengths_and_rank_sharding(monkeypatch, tmp_path):
         assert len(open(os.path.join(t.results_dir, s.name + "_time.txt")).read().splitlines()) == len(s)
     # everything exists now: nothing left to do
     assert run_dataset_batched(ds, t, batch=3, params=_Params(), make_batched=_FakeBatched) == {}
+
+
+def test_batched_runner_frames_per_launch_writes_the_same_files(monkeypatch, tmp_path):
+    """frames_per_launch = 3: whole chunks through track_chunk, the tail frame by frame; same rows as one frame per launch."""
+    from vittracker_amd.evaluation import Tracker, get_dataset
+    from vittracker_amd.evaluation.running import run_dataset_batched
+    ds = get_dataset("synthetic:4x5")            # lengths 5,7,9,5
+    texts = []
+    for n in (1, 3):
+        monkeypatch.setenv("VITTRACK_SAVE_DIR", str(tmp_path / f"n{n}"))
+        t = Tracker("vit_dist", "vit_48_h32_noKD", "synthetic")
+        _FakeBatched.instances.clear()
+        run_dataset_batched(ds, t, batch=4, params=_Params(), make_batched=_FakeBatched, frames_per_launch=n)
+        fb = _FakeBatched.instances[0]
+        assert fb.steps == 8 and getattr(fb, "chunks", 0) == (0 if n == 1 else 2)      # T = 9: 8 steps = 2 chunks of 3 + 2 single
+        texts.append([open(os.path.join(t.results_dir, s.name + ".txt")).read() for s in ds])
+        for s in ds:
+            assert len(open(os.path.join(t.results_dir, s.name + "_time.txt")).read().splitlines()) == len(s)
+    assert texts[0] == texts[1]
 
 
 def test_deploy_wire_signature():

@@ -74,11 +74,13 @@ def _groups(dataset, batch):
             yield hw, seqs[i:i + batch]
 
 
-def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=None, make_batched=None):
+def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=None, make_batched=None, frames_per_launch=1):
     """Lock-step batched run of `tracker` (an evaluation.Tracker) over `dataset`.  Sequence s belongs to rank
     s % world.  Ragged lengths: a finished sequence keeps receiving its last frame (its extra outputs are dropped).
     Per-frame time written for a sequence = wall time of the lock-step step / live sequences in that step (amortised:
-    there is no per-sequence call to time).  Returns {seq.name: output dict} for this rank's sequences."""
+    there is no per-sequence call to time).  frames_per_launch > 1: that many frames are read ahead and tracked by one
+    graph launch (BatchedVitTracker.track_chunk; same boxes, the files come out identical).
+    Returns {seq.name: output dict} for this rank's sequences."""
     from ..parallel import shard_sequences
     mine = [dataset[i] for i in shard_sequences(len(dataset), rank, world)]
     todo = [s for s in mine if not results_exist(tracker.results_dir, s)]
@@ -99,16 +101,23 @@ def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=Non
         dt = (time.time() - t0) / B
         for s in seqs:
             out[s.name]["time"].append(dt)
-        for t in range(1, T):
-            live = [s for s in seqs if t < len(s)]
+        n = max(1, int(frames_per_launch))
+        t = 1
+        while t < T:
+            k = n if (n > 1 and t + n <= T and hasattr(bt, "track_chunk")) else 1      # whole chunks, then frame by frame
             t0 = time.time()
-            r = bt.track(np.stack([frame(s, t) for s in seqs]))       # sync=True: boxes on the host
-            dt = (time.time() - t0) / len(live)
-            boxes = r["target_bbox"].numpy()
-            for b, s in enumerate(seqs):
-                if t < len(s):
-                    out[s.name]["target_bbox"].append(boxes[b].tolist())
-                    out[s.name]["time"].append(dt)
+            if k == 1:
+                boxes = bt.track(np.stack([frame(s, t) for s in seqs]))["target_bbox"].numpy()[None]     # sync=True: boxes on the host
+            else:
+                boxes = bt.track_chunk(np.stack([np.stack([frame(s, t + j) for s in seqs]) for j in range(k)]))["target_bbox"].numpy()
+            wall = (time.time() - t0) / k
+            for j in range(k):
+                live = sum(1 for s in seqs if t + j < len(s))
+                for b, s in enumerate(seqs):
+                    if t + j < len(s):
+                        out[s.name]["target_bbox"].append(boxes[j, b].tolist())
+                        out[s.name]["time"].append(wall / live)
+            t += k
         for s in seqs:
             save_tracker_output(s, tracker.results_dir, out[s.name])
             print("Tracker: {} {} {} ,  Sequence: {}  FPS: {}".format(tracker.name, tracker.parameter_name, tracker.run_id, s.name,
