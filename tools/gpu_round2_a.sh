@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 checkpoint A: GPU tests, bench line, kernel-trace stats at G128 and G256 (B=256)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r2a; mkdir -p $O
+O=$R/gpurun_out/r2a; rm -rf $O; mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/pytest.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err
