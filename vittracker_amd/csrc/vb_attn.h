@@ -47,6 +47,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     const bf16* kf = qf + C;
     const bf16* vf = vt + ((size_t)f * C + h * HD) * L;
 
+    const int l15 = lane & 15, q = lane >> 4;
+    // Q fragments live across passes: the first pass's are requested before the K / V^T staging (oldest in vmcnt order: the
+    // K-only wait below covers them), the NEXT pass's into the same registers as soon as a pass's q.k products are done
+    // (they are dead from there on), so their global-load latency is covered by softmax + P.V
+    bf16x8 qfrag[2][G::KS];
+    auto load_q = [&](int qt, bf16x8 (&dst)[G::KS]) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+            dst[ks] = *reinterpret_cast<const bf16x8*>(qf + (size_t)(qt * 16 + l15) * 2 * C + ks * 32 + q * 8);
+    };
+    load_q(w, qfrag[0]);
+    load_q(w + 4, qfrag[1]);
     // ---- stage K (rows permuted) and V^T
     const int pl = vbg::swz_byte(lane * 16), prow = pl >> 6, pk = (pl & 63) >> 1;
     for (int s = w; s < G::K_SUB; s += 4) {
@@ -66,25 +78,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     __syncthreads();
     bool v_ready = false;
 
-    const int l15 = lane & 15, q = lane >> 4;
     const int fr = vbg::swz_byte(l15 * 64 + q * 16);
     constexpr float LOG2E = 1.4426950408889634f;
     // NQ query tiles at once: every K / V^T fragment read from LDS feeds NQ MFMAs.  With one tile per pass the kernel issues one
     // ds_read_b128 per MFMA -- 256 B/clk/CU for four SIMDs' worth of 16-cycle MFMAs is exactly the LDS bandwidth, so it was
     // LDS-bound; two tiles halve the reads (a wave's five tiles go as 2 + 2 + 1).
-    auto pass = [&](auto nq_tag, int qt0, int qt1) {
-        constexpr int NQ = decltype(nq_tag)::value;
+    auto pass = [&](auto nq_tag, int qt0, int qt1, auto nxt_tag, int nx0, int nx1) {
+        constexpr int NQ = decltype(nq_tag)::value, NXT = decltype(nxt_tag)::value;
         const int qts[2] = {qt0, qt1};
         // the K / V^T fragments do not depend on the query tile: without this the compiler hoists all 80 ds_reads
         // (320 VGPRs) out of the loop and spills them
         int frq = fr;
         asm volatile("" : "+v"(frq));
-        bf16x8 qfrag[NQ][G::KS];
-#pragma unroll
-        for (int u = 0; u < NQ; ++u)
-#pragma unroll
-            for (int ks = 0; ks < G::KS; ++ks)
-                qfrag[u][ks] = *reinterpret_cast<const bf16x8*>(qf + (size_t)(qts[u] * 16 + l15) * 2 * C + ks * 32 + q * 8);
         f4 S[NQ][G::NT];
 #pragma unroll
         for (int t = 0; t < G::NT; ++t) {
@@ -97,25 +102,34 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
                 for (int u = 0; u < NQ; ++u) S[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf8, qfrag[u][ks], S[u][t], 0, 0, 0);
             }
         }
+        if constexpr (NXT >= 1) load_q(nx0, qfrag[0]);
+        if constexpr (NXT >= 2) load_q(nx1, qfrag[1]);
         float inv[NQ];
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            float mx = hmax4(S[u][0]);
+            // row maximum on v_max3_f32 (two values per instruction, two chains); exponent argument and row sum on packed
+            // f32 math (v_pk_fma_f32 / v_pk_add_f32): per query tile 80 exp + ~140 other VALU instead of ~310
+            float m0 = fmaxf(S[u][0].x, S[u][0].y), m1 = fmaxf(S[u][0].z, S[u][0].w);
 #pragma unroll
-            for (int t = 1; t < G::NT; ++t) mx = fmaxf(mx, hmax4(S[u][t]));
-            mx = quad_max(mx);
-            const float mb = mx * LOG2E;
-            float sum = 0.f;
+            for (int t = 1; t < G::NT; ++t) {
+                m0 = fmaxf(fmaxf(m0, S[u][t].x), S[u][t].y);
+                m1 = fmaxf(fmaxf(m1, S[u][t].z), S[u][t].w);
+            }
+            const float mx = quad_max(fmaxf(m0, m1));
+            const vbg::f2 l2 = {LOG2E, LOG2E}, nmb = {-mx * LOG2E, -mx * LOG2E};
+            vbg::f2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < G::NT; ++t) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[u][t][r], LOG2E, -mb));
-                    S[u][t][r] = p;
-                    sum += p;
-                }
+                const vbg::f2 a = __builtin_elementwise_fma(vbg::f2{S[u][t].x, S[u][t].y}, l2, nmb);
+                const vbg::f2 b = __builtin_elementwise_fma(vbg::f2{S[u][t].z, S[u][t].w}, l2, nmb);
+                const vbg::f2 pa = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                const vbg::f2 pb = {__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)};
+                S[u][t] = f4{pa.x, pa.y, pb.x, pb.y};
+                s0 += pa;
+                s1 += pb;
             }
-            inv[u] = 1.0f / quad_sum(sum);
+            const vbg::f2 st = s0 + s1;
+            inv[u] = 1.0f / quad_sum(st.x + st.y);
         }
         f4 O[NQ][G::DT];
 #pragma unroll
@@ -149,9 +163,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
             for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = vbg::to_bf16x4(O[u][dt] * splat4(inv[u]));
         }
     };
-    int qt = w;
-    for (; qt + 4 < G::NT; qt += 8) pass(std::integral_constant<int, 2>{}, qt, qt + 4);
-    if (qt < G::NT) pass(std::integral_constant<int, 1>{}, qt, qt);
+    // a wave's query tiles w, w + 4, ... go two per pass (plus a last single one when their number is odd)
+    constexpr int TPW = G::NT / 4;                      // query tiles per wave
+    static_assert(G::NT % 4 == 0 && TPW >= 2, "query tiles divide over the four waves");
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int i = 0; i + 1 < TPW; i += 2) {
+        const int qt = w + 4 * i, left = TPW - (i + 2);                      // tiles left after this pass
+        if (left >= 2) pass(I2{}, qt, qt + 4, I2{}, qt + 8, qt + 12);
+        else if (left == 1) pass(I2{}, qt, qt + 4, I1{}, qt + 8, qt + 8);
+        else pass(I2{}, qt, qt + 4, I0{}, 0, 0);
+    }
+    if constexpr (TPW % 2 == 1) pass(I1{}, w + 4 * (TPW - 1), 0, I0{}, 0, 0);
 }
 
 }  // namespace vba
