@@ -80,3 +80,16 @@ def test_deploy_session_matches_reference_golden_maps():
         sess.run(None, {"template": z})
     with pytest.raises(ValueError, match="Invalid output name"):
         sess.run(["output4"], {"template": z, "search": x})
+
+
+def test_bench_record_graph_form_on_one_gpu():
+    """The launch form bench.py uses for N > 1 (graphs writing their result records straight into the all_gather buffers, S steps
+    per launch + single-step remainder) run on one GPU without a communicator: records == plain forward (bench checks), rc 0."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--record-graphs", "--steps", "11", "--warmup", "3", "--batch", "32",
+                        "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["checked"] and j["value"] > 0 and j["config"]["steps_per_graph"] == 4 and j["steps"] == 11
