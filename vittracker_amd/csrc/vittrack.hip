@@ -253,7 +253,8 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
         if (r2 < 1 || r4 < 1 || (T / 4) % r2 || (T / 16) % r4 || (r2 * (T / 4)) % 256 || !(nt4 == 1 || nt4 == 2 || nt4 == 4) ||
             (r4 * (T / 16)) % 16 || (((2 * r4 + 1) * (T / 8)) % 16 && ((2 * r4) * (T / 8)) % 16) ||
-            3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64)
+            3 * vts::stem_b_npix2(T / 4, r4) < 4 * nt4 * 3 * 64 ||
+            (T / 4) > 256 || (4 * r4 + 3) > 5 * (256 / (T / 4)))     // stem_b stages <= 5 layer-2 rows per thread and plane
             return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
     }
     const bool want_fused = m->stem_fused < 0 ? B > 80 : m->stem_fused != 0;

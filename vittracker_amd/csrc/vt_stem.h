@@ -431,15 +431,29 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
     if (!(skip & 1))
         for (int i = threadIdx.x; i < 3 * npix2 + 6 * npix3; i += 256) map2[i] = splat4(0.f);
     __syncthreads();
-    // layer-2 activations of the band -> map2 (rows outside the image stay zero)
-    if (!(skip & 2))
-    for (int i = threadIdx.x; i < NR2 * S2 * 3; i += 256) {
-        const int icq = i / (NR2 * S2), pc = i - icq * (NR2 * S2);
-        const int lr = pc / S2, col = pc - lr * S2;
-        const int r2 = r2_0 + lr;
-        if (r2 >= 0 && r2 < S2) {
-            const f4 v = ld4(in + ((((size_t)b * 3 + icq) * S2 + r2) * S2 + col) * 4);
-            map2[icq * npix2 + lr * pitch2 + ((col & 1) ? half2 + 1 + (col >> 1) : (col >> 1))] = v;
+    // layer-2 activations of the band -> map2 (rows outside the image stay zero).  A thread keeps one column and walks rows
+    // (S2 is a power of two: 256 threads = 256 / S2 whole rows per step), so the index arithmetic is shifts and adds -- as a flat
+    // loop over (plane, row, column) with run-time divisors it was ~40 VALU instructions per element, more issue time than the
+    // band's MFMAs -- and a plane's loads are all in flight before the first store.
+    if (!(skip & 2)) {
+        const int lg2 = ilog2(S2);
+        const int col = threadIdx.x & (S2 - 1), rsub = threadIdx.x >> lg2, rstep = 256 >> lg2;
+        const int cpos = (col & 1) ? half2 + 1 + (col >> 1) : (col >> 1);
+        constexpr int MAXR = 5;                                   // rows per thread and plane: ceil(19 / 4), ceil(19 / 8)
+#pragma unroll 1                                                  // one plane's 5 loads in flight: 3 x 5 cost a workgroup per CU in VGPRs
+        for (int icq = 0; icq < 3; ++icq) {
+            const float* src = in + (((size_t)b * 3 + icq) << (2 * lg2)) * 4 + col * 4;
+            f4 v[MAXR];
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) {
+                const int lr = rsub + j * rstep, r2 = r2_0 + lr;
+                if (lr < NR2 && r2 >= 0 && r2 < S2) v[j] = ld4(src + ((size_t)r2 << lg2) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < MAXR; ++j) {
+                const int lr = rsub + j * rstep, r2 = r2_0 + lr;
+                if (lr < NR2 && r2 >= 0 && r2 < S2) map2[icq * npix2 + lr * pitch2 + cpos] = v[j];
+            }
         }
     }
     const int c4_0 = (NCH4 * wave) >> 2, c4_n = ((NCH4 * (wave + 1)) >> 2) - c4_0;     // 3, 4, 3, 4 chunks
