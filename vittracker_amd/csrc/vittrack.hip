@@ -85,6 +85,7 @@ struct vt_model {
     // fills the chip; below that the multi-workgroup forms spread a frame over several CUs (measured, us per step, tools/
     // small_batch_sweep.py: G128 B=1 97.6 -> 81.1, B=64 100.4 -> 86.1; G256 B=1 337 -> 287; crossovers at the thresholds below).
     int head_fused = -1;   // F = 8: head_fused_kernel (towers + decode in one workgroup per frame); auto: B > 176
+                           // F = 16: head_seq_kernel (one workgroup per frame runs the three towers in turn, then decodes); auto: B > 176
     int stem_pipe = -1;    // G256: stem_pipe_kernel (layers 1 + 2 per frame) instead of stem_a; auto: B > 176
     int stem_fused = -1;   // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b; auto: B > 80
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
@@ -395,6 +396,16 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         else
             hipLaunchKernelGGL((vth::head_towers_kernel<8, 4, false>), dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st, feat, m->head.p,
                                score, size, offset, m->skip_head);
+    } else if (m->F == 16 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
+        // one workgroup per frame: the three towers in turn on one staged input map, decode from LDS (no decode launch)
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(512), vth::SeqHeadGeo<16>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
+                               size, offset, pred, hann, conf, m->skip_head);
+        };
+        if (m->skip_head) go(&vth::head_seq_kernel<16, 8, true>);
+        else go(&vth::head_seq_kernel<16, 8, false>);
+        HIP_TRY(hipGetLastError());
+        return VT_OK;
     } else if (m->F == 16) {
         // 129 KB of LDS per tower = one workgroup per CU: 8 waves give every SIMD two instruction streams
         if (m->skip_head)
@@ -621,6 +632,12 @@ int vt_create(const vt_config* cfg, vt_model** out) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
         if (e == hipSuccess)
             e = allow_stem_lds();
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_seq_kernel<16, 8, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::SeqHeadGeo<16>::LDS_BYTES));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_seq_kernel<16, 8, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::SeqHeadGeo<16>::LDS_BYTES));
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));

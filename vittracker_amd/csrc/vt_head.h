@@ -382,4 +382,117 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ head_seq
+// F = 16 (129 KB of maps: one workgroup per CU whatever the form): one workgroup per FRAME runs the three towers one after
+// the other on ONE staged input map and decodes from LDS -- instead of three workgroups per frame (head_towers) that each clear
+// and stage the same 48-channel map, plus a decode launch.  Same arithmetic in the same order as head_towers + decode.
+template <int F>
+struct SeqHeadGeo {
+    using G = Geo<F>;
+    static constexpr int OUT_FLOATS = 5 * F * F;                               // score, size x2, offset x2
+    static constexpr int LDS_BYTES = G::LDS_BYTES + OUT_FLOATS * 4;
+};
+
+template <int F, int NW, bool DIAG = false>
+__global__ __launch_bounds__(NW * 64) void head_seq_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                       const float* __restrict__ window, float* __restrict__ score,
+                                                       float* __restrict__ size, float* __restrict__ offset,
+                                                       float* __restrict__ pred, float* __restrict__ hann,
+                                                       float* __restrict__ conf, int skip_arg) {   // skip: diagnostic
+    using G = Geo<F>;
+    const int skip = DIAG ? skip_arg : 0;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    f4* in_map = reinterpret_cast<f4*>(sm);            // 12 quads
+    f4* m1 = in_map + (C / 4) * G::NPIX;               // 8 quads
+    f4* m2 = m1 + (W1 / 4) * G::NPIX;                  // 4 quads
+    float* outs = reinterpret_cast<float*>(m2 + 4 * G::NPIX);   // [5][F*F]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int n = F * F;
+
+    HeadConv<C, W1, F, NW> c1;
+    HeadConv<W1, 16, F, NW> c2;
+    HeadConv<16, 8, F, NW> c3;
+    HeadConv<8, 4, F, NW> c4;
+    c1.prefetch(hw + O_W1, wave, lane);        // first weight burst flies during the map set-up
+    if (!(skip & 1))
+        for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += NW * 64) in_map[i] = splat4(0.f);
+    __syncthreads();
+    // (B,HW,C) tokens -> quad planes, once for the three towers   (vit_dist.py:126-129)
+    if (!(skip & 2))
+        for (int i = threadIdx.x; i < n * (C / 4); i += NW * 64) {
+            const int icq = i / n, pix = i % n;
+            in_map[icq * G::NPIX + G::interior(pix / F, pix % F)] = ld4(feat + ((size_t)b * n + pix) * C + 4 * icq);
+        }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {              // tower 0 = ctr, 1 = offset, 2 = size
+        const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
+        c2.prefetch(tw + O_W2, wave, lane);    // each layer's first burst is requested a layer early
+        if (!(skip & 4)) c1.run(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
+        c3.prefetch(tw + O_W3, wave, lane);
+        __syncthreads();
+        if (!(skip & 8)) c2.run(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
+        c4.prefetch(tw + O_W4, wave, lane);
+        __syncthreads();
+        if (!(skip & 16)) c3.run(m2, m1, tw + O_W3, tw + O_B3, wave, lane);
+        __syncthreads();
+        if (!(skip & 16)) c4.run(m1, m2, tw + O_W4, tw + O_B4, wave, lane);
+        if (t < 2) c1.prefetch(tw + TOWER_STRIDE + O_W1, wave, lane);   // the next tower's first burst
+        __syncthreads();
+        // 1x1 conv + activation (head.py:187,194,200-201) -> global maps and the LDS copy for the decode
+        for (int pix = threadIdx.x; pix < n; pix += NW * 64) {
+            const f4 v = m2[G::interior(pix / F, pix % F)];
+            const int nout = (t == 0) ? 1 : 2;
+            for (int o = 0; o < nout; ++o) {
+                const f4 w5 = ld4(tw + O_W5 + 4 * o);
+                float y = tw[O_B5 + o];
+                y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
+                if (t == 0) { y = sigmoid_clamped(y); score[(size_t)b * n + pix] = y; outs[pix] = y; }
+                else if (t == 2) { y = sigmoid_clamped(y); size[((size_t)b * 2 + o) * n + pix] = y; outs[(1 + o) * n + pix] = y; }
+                else { offset[((size_t)b * 2 + o) * n + pix] = y; outs[(3 + o) * n + pix] = y; }
+            }
+        }
+        // the next tower's conv1 writes m1 (last read by c4, before the barrier above) and its conv2 writes m2 only after
+        // the barrier that follows conv1: the 1x1 reads of m2 above need no barrier of their own
+    }
+    __syncthreads();
+    // cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105)
+    if (wave == 0) {
+        float v0 = -3.0e38f, v1 = -3.0e38f;
+        int i0 = 0x7fffffff, i1 = 0x7fffffff;
+        for (int i = lane; i < n; i += 64) {
+            const float sc = outs[i];
+            argmax_merge(v0, i0, sc, i);
+            if (window != nullptr) argmax_merge(v1, i1, window[i] * sc, i);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
+            argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
+        }
+        if (i0 >= n) i0 = 0;      // a map of NaNs never beats the initial value: keep the gathers in bounds (as decode_kernel)
+        if (i1 >= n) i1 = 0;
+        if (lane == 0) {
+            const float fF = (float)F;
+            const float* sz = outs + n;
+            const float* of = outs + 3 * n;
+            if (pred != nullptr) {
+                pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
+                pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
+                pred[b * 4 + 2] = sz[i0];
+                pred[b * 4 + 3] = sz[n + i0];
+            }
+            if (hann != nullptr && window != nullptr) {
+                hann[b * 4 + 0] = ((float)(i1 % F) + of[i1]) / fF;
+                hann[b * 4 + 1] = ((float)(i1 / F) + of[n + i1]) / fF;
+                hann[b * 4 + 2] = sz[i1];
+                hann[b * 4 + 3] = sz[n + i1];
+            }
+            if (conf != nullptr) conf[b] = v0;
+        }
+    }
+}
+
 }  // namespace vth
