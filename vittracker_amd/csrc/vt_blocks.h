@@ -228,6 +228,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     const int tok = lane & 15, q = lane >> 4;
     const int g = w - (NT - 1);                            // BAL: guest index of waves >= NT-1
     const float scale = 0.14433756729740643f;  // 48^-0.5  (head_dim ** -0.5, attn.py:15)
+    constexpr float SCALE_LOG2E = 0.14433756729740643f * 1.4426950408889634f;
     const int guest_prio = dbg_skip_tile == -3 ? 0 : 1;   // -3: experiment, guests at default priority
     const bool fine = dbg_skip_tile == -2 || dbg_skip_tile <= -100;          // -2: per-stage stamps; -(100 + t): per-stage stamps and tile t skipped
     if (dbg_skip_tile <= -100) dbg_skip_tile = -100 - dbg_skip_tile;
@@ -379,8 +380,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
             if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+                // softmax((q k^T) * scale) (attn.py:40-41) as exp2(raw * (scale log2 e) - max_raw * (scale log2 e)): the scale, the
+                // subtraction and exp's own log2 e factor become ONE packed fma per two scores, the row maximum runs on v_max3 and the
+                // row sum on packed adds -- 10 instead of 22 VALU instructions per score tile (scale > 0: the raw maximum is the maximum)
                 f4 s[NT];
-                float m = -3.0e38f;
+                float m0 = -3.0e38f, m1 = -3.0e38f;
                 constexpr int JG = 5;                    // key tiles per group = independent chains
                 static_assert(NT % JG == 0, "NT must be a multiple of 5");
 #pragma unroll
@@ -396,22 +400,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         [&](int c) { return qr[i][c]; }, acc);
 #pragma unroll
                     for (int j = 0; j < JG; ++j) {
-                        acc[j] = acc[j] * splat4(scale);     // (q @ k^T) * scale, attn.py:40
                         s[j0 + j] = acc[j];
-                        m = fmaxf(m, hmax4(acc[j]));
+                        m0 = fmaxf(fmaxf(m0, acc[j].x), acc[j].y);
+                        m1 = fmaxf(fmaxf(m1, acc[j].z), acc[j].w);
                     }
                 }
                 fstamp();
-                m = quad_max(m);
-                float den = 0.f;
+                const float m = quad_max(fmaxf(m0, m1));
+                const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m * SCALE_LOG2E, -m * SCALE_LOG2E};
+                f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
 #pragma unroll
                 for (int J = 0; J < NT; ++J) {
-                    f4 e;
-                    e.x = __expf(s[J].x - m); e.y = __expf(s[J].y - m);
-                    e.z = __expf(s[J].z - m); e.w = __expf(s[J].w - m);
-                    s[J] = e;
-                    den += hsum4(e);
+                    const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
+                    const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
+                    const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                    const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                    s[J] = f4{ea.x, ea.y, ec.x, ec.y};
+                    d0 += ea;
+                    d1 += ec;
                 }
+                const f2 dd = d0 + d1;
+                const float den = dd.x + dd.y;
                 const float rden = __builtin_amdgcn_rcpf(quad_sum(den));     // v_rcp_f32: 1 ulp
                 fstamp();
                 f4 o[NC];
@@ -453,22 +462,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                             for (int j = 0; j < NJ; ++j) a[j] = Kimg[((J0 + j) * NC + c) * 64 + lane];
                         },
                         [&](int c) { return qv[c]; }, sc);
-                    float m = -3.0e38f;
+                    float m0 = -3.0e38f, m1 = -3.0e38f;          // raw scores, as in the owners' path
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        sc[j] = sc[j] * splat4(scale);
-                        m = fmaxf(m, hmax4(sc[j]));
+                        m0 = fmaxf(fmaxf(m0, sc[j].x), sc[j].y);
+                        m1 = fmaxf(fmaxf(m1, sc[j].z), sc[j].w);
                     }
-                    m = quad_max(m);
-                    float den = 0.f;
+                    const float mraw = quad_max(fmaxf(m0, m1));
+                    const float m = mraw * scale;                 // published in natural-log units: the merge uses exp(m_k - M)
+                    const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-mraw * SCALE_LOG2E, -mraw * SCALE_LOG2E};
+                    f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        f4 e;
-                        e.x = __expf(sc[j].x - m); e.y = __expf(sc[j].y - m);
-                        e.z = __expf(sc[j].z - m); e.w = __expf(sc[j].w - m);
-                        sc[j] = e;
-                        den += hsum4(e);
+                        const f2 a = __builtin_elementwise_fma(f2{sc[j].x, sc[j].y}, k2, nm2);
+                        const f2 c = __builtin_elementwise_fma(f2{sc[j].z, sc[j].w}, k2, nm2);
+                        const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                        const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                        sc[j] = f4{ea.x, ea.y, ec.x, ec.y};
+                        d0 += ea;
+                        d1 += ec;
                     }
+                    const f2 dd = d0 + d1;
+                    float den = dd.x + dd.y;
                     den = quad_sum(den);
                     f4 o[NC];
 #pragma unroll

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define VT_WAVE 64
 
