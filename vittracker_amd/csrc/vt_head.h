@@ -314,15 +314,18 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
     HeadConv<16, 8, F> c3;
     HeadConv<8, 4, F> c4;
     c1.prefetch(tw + O_W1, wv, lane);
+    // (B,HW,C) tokens -> quad planes, once for all towers (vit_dist.py:126-129): exactly one float4 per thread, requested
+    // before the LDS is cleared so that its L2 round trip runs under the clear and the barrier; the decode's window value too
+    static_assert(F * F * (C / 4) == 768, "one staged element per thread");
+    const int icq_s = threadIdx.x / (F * F), pix_s = threadIdx.x % (F * F);
+    f4 fv = splat4(0.f);
+    if (!(skip & 2)) fv = ld4(feat + ((size_t)b * F * F + pix_s) * C + 4 * icq_s);
+    float win = 0.f;
+    if (wave == 0 && window != nullptr) win = window[lane];
     if (!(skip & 1))
         for (int i = threadIdx.x; i < (C / 4) * G::NPIX + 3 * FG::TOWER_F4; i += 768) in_map[i] = splat4(0.f);
     __syncthreads();
-    // (B,HW,C) tokens -> quad planes, once for all towers   (vit_dist.py:126-129)
-    if (!(skip & 2))
-    for (int i = threadIdx.x; i < F * F * (C / 4); i += 768) {
-        const int icq = i / (F * F), pix = i % (F * F);
-        in_map[icq * G::NPIX + G::interior(pix / F, pix % F)] = ld4(feat + ((size_t)b * F * F + pix) * C + 4 * icq);
-    }
+    if (!(skip & 2)) in_map[icq_s * G::NPIX + G::interior(pix_s / F, pix_s % F)] = fv;
     __syncthreads();
     c2.prefetch(tw + O_W2, wv, lane);
     if (!(skip & 4)) c1.run(in_map, m1, tw + O_W1, tw + O_B1, wv, lane);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
     // cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105)
     if (wave == 0) {
         const float sc = outs[lane];
-        float v0 = sc, v1 = window != nullptr ? window[lane] * sc : -3.0e38f;
+        float v0 = sc, v1 = window != nullptr ? win * sc : -3.0e38f;
         int i0 = lane, i1 = lane;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(NW * 64) void head_seq_kernel(const float* __restri
         for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += NW * 64) in_map[i] = splat4(0.f);
     __syncthreads();
     // (B,HW,C) tokens -> quad planes, once for the three towers   (vit_dist.py:126-129)
+    // (requesting these before the clear, as head_fused does, measured 1 % slower here: six float4 per thread held over the clear)
     if (!(skip & 2))
         for (int i = threadIdx.x; i < n * (C / 4); i += NW * 64) {
             const int icq = i / n, pix = i % n;
