@@ -64,6 +64,7 @@ struct vt_model {
     bool weights_loaded = false;
     // parameters on the device
     DevBuf stem_w[4], stem_b[4];     // folded, [group][tap][cin][OCG] / [cout]
+    DevBuf stem_w2k;                 // layer 2 again as [tap][16 output channels][8 input channels] for the 4-block f32 MFMA
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
     DevBuf head;                     // 3 * TOWER_STRIDE
@@ -266,7 +267,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
                                m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p,
-                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps);
+                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_fused_kernel<0, true>);
@@ -282,7 +283,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds_p, st, z, x, m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p,
-                               m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps);
+                               m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_pipe_kernel<256, 128, 0, true>);
@@ -658,6 +659,7 @@ void vt_destroy(vt_model* m) {
     if (!m) return;
     if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
+    m->stem_w2k.release();
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
@@ -700,6 +702,14 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             for (int o = 0; o < STEM_CH[i + 1]; ++o) bias[o] = (float)b[o];
             if ((rc = upload(m->stem_w[i], img))) return rc;
             if ((rc = upload(m->stem_b[i], bias))) return rc;
+            if (i == 1) {   // [tap][16 oc][8 ic]: element = w[oc][ic][tap], zero beyond 12 x 6
+                std::vector<float> k((size_t)9 * 16 * 8, 0.f);
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int oc = 0; oc < STEM_CH[2]; ++oc)
+                        for (int ic = 0; ic < STEM_CH[1]; ++ic)
+                            k[((size_t)tap * 16 + oc) * 8 + ic] = (float)w[((size_t)oc * STEM_CH[1] + ic) * 9 + tap];
+                if ((rc = upload(m->stem_w2k, k))) return rc;
+            }
         }
     }
     const float* p;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
     const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
     const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip_arg,
-    unsigned long long* __restrict__ stamps) {     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    unsigned long long* __restrict__ stamps,       // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    const float* __restrict__ w2k) {               // layer-2 weights as [tap][16 output channels][8] (f32 build)
     using G = FusedGeo;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
     const int skip = DIAG ? skip_arg : 0;
@@ -177,6 +178,51 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
 
     // ---- layer 2: this group's ring -> the frame's layer-2 map ------------------------------------------
     auto layer2 = [&](const auto& J) {
+#ifndef VT_F16
+        // Layer 2 on v_mfma_f32_16x16x1_4B_f32: four 16x16 blocks per instruction, K = 1.  Its 6 input channels make 54 real
+        // k-steps; on the 16x16x4 form (k in quads of 4 channels, chunks of 4 quads) they pad to 80.  Block b = pixel tile 4 gw + b:
+        // lane (b, px) SUPPLIES pixel px of that tile as B, every lane supplies W[oc = px][k] as A (the same for the four
+        // blocks), and lane (q, px) RECEIVES channels 4q..4q+3 of pixel px of all four tiles (tools/src/probe_mfma4b.hip).
+        // Four waves of the group (one per SIMD) cover the band's 16 tiles; the other four go straight to the barrier.
+        if (gw < 4) {
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            const int op = 16 * (4 * gw + q) + px, yy = op >> J.lgW2, xx = op & ((1 << J.lgW2) - 1);
+            const f4* src = ring + 2 * yy * J.PITCH + xx;                     // tap (0,0) of this lane's pixel, channel quad 0
+            const f4* wk = cw2 + 2 * px;                                      // [tap][16 output channels][2 float4]
+            const f4 bv2 = ld4(cb2 + 4 * q);
+            f16v acc = {bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w};
+            auto tapoff = [&](int tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                return dy * J.PITCH + (dx == 1 ? 0 : (dx == 0 ? J.HALF : J.HALF + 1));
+            };
+            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[1];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                f4 na0 = a0, na1 = a1, nw0 = w0, nw1 = w1;
+                if (tap + 1 < 9) {
+                    na0 = src[tapoff(tap + 1)]; na1 = src[J.npix1 + tapoff(tap + 1)];
+                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 1];
+                    __builtin_amdgcn_sched_barrier(0);        // keep the next tap's reads ahead of this tap's MFMAs
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.x, a0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.y, a0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.z, a0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.w, a0.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w1.x, a1.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w1.y, a1.y, acc, 0, 0, 0);
+                a0 = na0; a1 = na1; w0 = nw0; w1 = nw1;
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int ob = 16 * (4 * gw + bb) + px, y = ob >> J.lgW2, x = ob & ((1 << J.lgW2) - 1);
+                    f4 r = {acc[4 * bb], acc[4 * bb + 1], acc[4 * bb + 2], acc[4 * bb + 3]};
+                    r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                    m2[J.m2_off + q * J.npix2 + (J.p0 + y + 1) * J.pitch2 + ((x & 1) ? J.half2 + 1 + (x >> 1) : (x >> 1))] = r;
+                }
+            }
+        }
+#else
         f4 w2a[5][1];
 #pragma unroll
         for (int c = 0; c < 5; ++c) w2a[c][0] = cw2[c * 64 + lane];
@@ -200,6 +246,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                 m2[J.m2_off + q * J.npix2 + (J.p0 + yy[i] + 1) * J.pitch2 + ((x & 1) ? J.half2 + 1 + (x >> 1) : (x >> 1))] = v;
             }
         }
+#endif
     };
 
     int nstamp = 0;
@@ -220,7 +267,12 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     {   // constants -> LDS; zero only what is read without ever being written: the top rows of the rings,
         // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
         const int t = threadIdx.x;
+#ifndef VT_F16
+        if (t < 9 * 32) cw2[t] = ld4(w2k + 4 * t);           // [tap][16][8] floats: layer-2 weights for the 4-block MFMA
+#else
         if (t < 5 * 64) cw2[t] = ld4(w2img + 4 * t);
+#endif
+        else if (t < 5 * 64) {}
         else if (t < 5 * 64 + 4) cw2[t] = ld4(b2 + 4 * (t - 320));
         else if (t < 5 * 64 + 12) cw2[t] = ld4(b3 + 4 * (t - 324));
         else if (t < 5 * 64 + 24) cw2[t] = ld4(b4 + 4 * (t - 332));
@@ -376,7 +428,8 @@ template <int TX, int TZ, int ZMODE, bool DIAG>
 __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip_arg,
-    unsigned long long* __restrict__ stamps) {   // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
+    const float* __restrict__ w2k) {             // layer-2 weights as [tap][16 output channels][8] (f32 build)
     // ZMODE 0: both crops; 1: search bands only (template cached downstream); 2: template bands only.  DIAG: see stem_fused_kernel.
     using G = PipeGeo<TX, TZ>;
     const int skip = DIAG ? skip_arg : 0;
@@ -470,6 +523,51 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
         __builtin_amdgcn_s_setprio(0);
     };
     auto layer2 = [&](const Band& J) {
+#ifndef VT_F16
+        // Layer 2 on v_mfma_f32_16x16x1_4B_f32: four 16x16 blocks per instruction, K = 1.  Its 6 input channels make 54 real
+        // k-steps; on the 16x16x4 form (k in quads of 4 channels, chunks of 4 quads) they pad to 80.  Block b = pixel tile 4 gw + b:
+        // lane (b, px) SUPPLIES pixel px of that tile as B, every lane supplies W[oc = px][k] as A (the same for the four
+        // blocks), and lane (q, px) RECEIVES channels 4q..4q+3 of pixel px of all four tiles (tools/src/probe_mfma4b.hip).
+        // Four waves of the group (one per SIMD) cover the band's 16 tiles; the other four go straight to the barrier.
+        if (gw < 4) {
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            const int op = 16 * (4 * gw + q) + px, yy = op >> J.lgW2, xx = op & ((1 << J.lgW2) - 1);
+            const f4* src = ring + 2 * yy * J.PITCH + xx;                     // tap (0,0) of this lane's pixel, channel quad 0
+            const f4* wk = cw2 + 2 * px;                                      // [tap][16 output channels][2 float4]
+            const f4 bv2 = ld4(cb2 + 4 * q);
+            f16v acc = {bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w};
+            auto tapoff = [&](int tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                return dy * J.PITCH + (dx == 1 ? 0 : (dx == 0 ? J.HALF : J.HALF + 1));
+            };
+            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[1];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                f4 na0 = a0, na1 = a1, nw0 = w0, nw1 = w1;
+                if (tap + 1 < 9) {
+                    na0 = src[tapoff(tap + 1)]; na1 = src[J.npix1 + tapoff(tap + 1)];
+                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 1];
+                    __builtin_amdgcn_sched_barrier(0);        // keep the next tap's reads ahead of this tap's MFMAs
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.x, a0.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.y, a0.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.z, a0.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.w, a0.w, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w1.x, a1.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w1.y, a1.y, acc, 0, 0, 0);
+                a0 = na0; a1 = na1; w0 = nw0; w1 = nw1;
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int ob = 16 * (4 * gw + bb) + px, y = ob >> J.lgW2, x = ob & ((1 << J.lgW2) - 1);
+                    f4 r = {acc[4 * bb], acc[4 * bb + 1], acc[4 * bb + 2], acc[4 * bb + 3]};
+                    r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                    st4(J.out + ((((size_t)q << (2 * J.lgW2)) + (((size_t)J.p0 + y) << J.lgW2) + x) << 2), r);   // quad plane q
+                }
+            }
+        }
+#else
         f4 w2a[5][1];
 #pragma unroll
         for (int c = 0; c < 5; ++c) w2a[c][0] = cw2[c * 64 + lane];
@@ -492,6 +590,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
                 st4(J.out + ((((size_t)q << (2 * J.lgW2)) + (((size_t)J.p0 + yy[i]) << J.lgW2) + xx[i]) << 2), r);   // quad plane q
             }
         }
+#endif
     };
 
     int nstamp = 0;
@@ -508,7 +607,12 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     stamp();
     f4 v[3][3];
     fetch(band(2 * s_lo + grp), v);
+#ifndef VT_F16
+    if (threadIdx.x < 9 * 32) cw2[threadIdx.x] = ld4(w2k + 4 * threadIdx.x);     // [tap][16][8] floats
+#else
     if (threadIdx.x < 5 * 64) cw2[threadIdx.x] = ld4(w2img + 4 * threadIdx.x);
+#endif
+    else if (threadIdx.x < 5 * 64) {}
     else if (threadIdx.x < 5 * 64 + 4) cw2[threadIdx.x] = ld4(b2 + 4 * (threadIdx.x - 320));
     // group B works one interval behind group A; both execute NB + 1 barriers
     if (grp == 1) __syncthreads();
