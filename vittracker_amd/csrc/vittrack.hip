@@ -64,7 +64,7 @@ struct vt_model {
     bool weights_loaded = false;
     // parameters on the device
     DevBuf stem_w[4], stem_b[4];     // folded, [group][tap][cin][OCG] / [cout]
-    DevBuf stem_w2k;                 // layer 2 again as [tap][16 output channels][8 input channels] for the 4-block f32 MFMA
+    DevBuf stem_w2k;                 // layer 2 again as [tap][input-channel quad][16 output channels][4] for the 4-block f32 MFMA
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
     DevBuf head;                     // 3 * TOWER_STRIDE
@@ -702,12 +702,12 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             for (int o = 0; o < STEM_CH[i + 1]; ++o) bias[o] = (float)b[o];
             if ((rc = upload(m->stem_w[i], img))) return rc;
             if ((rc = upload(m->stem_b[i], bias))) return rc;
-            if (i == 1) {   // [tap][16 oc][8 ic]: element = w[oc][ic][tap], zero beyond 12 x 6
-                std::vector<float> k((size_t)9 * 16 * 8, 0.f);
+            if (i == 1) {   // [tap][ic / 4][16 oc][ic % 4]: element = w[oc][ic][tap], zero beyond 12 x 6
+                std::vector<float> k((size_t)9 * 2 * 16 * 4, 0.f);
                 for (int tap = 0; tap < 9; ++tap)
                     for (int oc = 0; oc < STEM_CH[2]; ++oc)
                         for (int ic = 0; ic < STEM_CH[1]; ++ic)
-                            k[((size_t)tap * 16 + oc) * 8 + ic] = (float)w[((size_t)oc * STEM_CH[1] + ic) * 9 + tap];
+                            k[(((size_t)tap * 2 + ic / 4) * 16 + oc) * 4 + ic % 4] = (float)w[((size_t)oc * STEM_CH[1] + ic) * 9 + tap];
                 if ((rc = upload(m->stem_w2k, k))) return rc;
             }
         }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
     const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip_arg,
     unsigned long long* __restrict__ stamps,       // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
-    const float* __restrict__ w2k) {               // layer-2 weights as [tap][16 output channels][8] (f32 build)
+    const float* __restrict__ w2k) {               // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
     using G = FusedGeo;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
     const int skip = DIAG ? skip_arg : 0;
@@ -188,20 +188,20 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             typedef float f16v __attribute__((ext_vector_type(16)));
             const int op = 16 * (4 * gw + q) + px, yy = op >> J.lgW2, xx = op & ((1 << J.lgW2) - 1);
             const f4* src = ring + 2 * yy * J.PITCH + xx;                     // tap (0,0) of this lane's pixel, channel quad 0
-            const f4* wk = cw2 + 2 * px;                                      // [tap][16 output channels][2 float4]
+            const f4* wk = cw2 + px;                                          // [tap][channels 0-3 | 4-5][16 output channels] float4: 16 lanes read 16 consecutive entries
             const f4 bv2 = ld4(cb2 + 4 * q);
             f16v acc = {bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w};
             auto tapoff = [&](int tap) {
                 const int dy = tap / 3, dx = tap - 3 * dy;
                 return dy * J.PITCH + (dx == 1 ? 0 : (dx == 0 ? J.HALF : J.HALF + 1));
             };
-            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[1];
+            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[16];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 f4 na0 = a0, na1 = a1, nw0 = w0, nw1 = w1;
                 if (tap + 1 < 9) {
                     na0 = src[tapoff(tap + 1)]; na1 = src[J.npix1 + tapoff(tap + 1)];
-                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 1];
+                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 16];
                     __builtin_amdgcn_sched_barrier(0);        // keep the next tap's reads ahead of this tap's MFMAs
                 }
                 acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.x, a0.x, acc, 0, 0, 0);
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
         const int t = threadIdx.x;
 #ifndef VT_F16
-        if (t < 9 * 32) cw2[t] = ld4(w2k + 4 * t);           // [tap][16][8] floats: layer-2 weights for the 4-block MFMA
+        if (t < 9 * 32) cw2[t] = ld4(w2k + 4 * t);           // [tap][2][16][4] floats: layer-2 weights for the 4-block MFMA
 #else
         if (t < 5 * 64) cw2[t] = ld4(w2img + 4 * t);
 #endif
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip_arg,
     unsigned long long* __restrict__ stamps,     // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
-    const float* __restrict__ w2k) {             // layer-2 weights as [tap][16 output channels][8] (f32 build)
+    const float* __restrict__ w2k) {             // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
     // ZMODE 0: both crops; 1: search bands only (template cached downstream); 2: template bands only.  DIAG: see stem_fused_kernel.
     using G = PipeGeo<TX, TZ>;
     const int skip = DIAG ? skip_arg : 0;
@@ -533,20 +533,20 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
             typedef float f16v __attribute__((ext_vector_type(16)));
             const int op = 16 * (4 * gw + q) + px, yy = op >> J.lgW2, xx = op & ((1 << J.lgW2) - 1);
             const f4* src = ring + 2 * yy * J.PITCH + xx;                     // tap (0,0) of this lane's pixel, channel quad 0
-            const f4* wk = cw2 + 2 * px;                                      // [tap][16 output channels][2 float4]
+            const f4* wk = cw2 + px;                                          // [tap][channels 0-3 | 4-5][16 output channels] float4: 16 lanes read 16 consecutive entries
             const f4 bv2 = ld4(cb2 + 4 * q);
             f16v acc = {bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w, bv2.x, bv2.y, bv2.z, bv2.w};
             auto tapoff = [&](int tap) {
                 const int dy = tap / 3, dx = tap - 3 * dy;
                 return dy * J.PITCH + (dx == 1 ? 0 : (dx == 0 ? J.HALF : J.HALF + 1));
             };
-            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[1];
+            f4 a0 = src[tapoff(0)], a1 = src[J.npix1 + tapoff(0)], w0 = wk[0], w1 = wk[16];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 f4 na0 = a0, na1 = a1, nw0 = w0, nw1 = w1;
                 if (tap + 1 < 9) {
                     na0 = src[tapoff(tap + 1)]; na1 = src[J.npix1 + tapoff(tap + 1)];
-                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 1];
+                    nw0 = wk[32 * (tap + 1)]; nw1 = wk[32 * (tap + 1) + 16];
                     __builtin_amdgcn_sched_barrier(0);        // keep the next tap's reads ahead of this tap's MFMAs
                 }
                 acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w0.x, a0.x, acc, 0, 0, 0);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     f4 v[3][3];
     fetch(band(2 * s_lo + grp), v);
 #ifndef VT_F16
-    if (threadIdx.x < 9 * 32) cw2[threadIdx.x] = ld4(w2k + 4 * threadIdx.x);     // [tap][16][8] floats
+    if (threadIdx.x < 9 * 32) cw2[threadIdx.x] = ld4(w2k + 4 * threadIdx.x);     // [tap][2][16][4] floats
 #else
     if (threadIdx.x < 5 * 64) cw2[threadIdx.x] = ld4(w2img + 4 * threadIdx.x);
 #endif
