@@ -32,14 +32,16 @@ def _video(n, H=240, W=320, seed=0):
     return frames, boxes
 
 
+@pytest.mark.parametrize("host_crop", [False, True])
 @pytest.mark.parametrize("yaml_name", ["vit_48_h32_noKD", "vit_48_h32_g128"])
-def test_track_matches_oracle_driven_tracker(yaml_name):
+def test_track_matches_oracle_driven_tracker(yaml_name, host_crop):
     import torch
     from oracle import vt_oracle_np as onp
     from vittracker_amd.host_ops import clip_box, sample_target
     from vittracker_amd.tracker.vit_dist import get_tracker_class
 
     p = _params(yaml_name)
+    p.host_crop = host_crop       # False (default): whole frame step on the device; True: the reference's host crop + one graph replay
     trk = get_tracker_class()(p, "synthetic")
     frames, boxes = _video(6)
     assert trk.initialize(frames[0], {"init_bbox": boxes[0]}) is None

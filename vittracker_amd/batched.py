@@ -3,8 +3,8 @@
 The reference runs one tracker object per sequence and per process
 (``lib/test/evaluation/tracker.py:90-152``, ``running.py:105-112``): per frame a host crop
 (cv2), an H2D copy, ~130 kernel launches and a ``.tolist()`` sync.  Here B sequences advance
-together: one H2D copy of the raw uint8 frames, then ``crop -> hipGraph(forward) -> state update``
-on the stream with no host synchronisation; boxes are read back whenever the caller wants them
+together: one H2D copy of the raw uint8 frames, then ``crop -> forward -> state update`` as one captured
+graph on the stream with no host synchronisation; boxes are read back whenever the caller wants them
 (every frame, or once at the end of the sequence).
 
 Semantics per sequence are those of ``Vit_dist.initialize / track``
@@ -61,22 +61,17 @@ class BatchedVitTracker:
         self.graph = None            # captured at the first initialize(): the forward reads the cached template (z = None)
         self._chunk_graphs = {}      # (frame buffer address, n, H, W) -> whole-step graph of n frames (track_chunk)
         self._chunk_buf = None
-        self._chunk_pinned = None
         self.frames = None
-        self._pinned = None
-        self._h2d_done = None
-        self._chunk_h2d = None
         self._slot = 0
         self.hw = None
         self.frame_id = 0
 
     def _upload(self, frames):
-        """Host frames go through two pinned staging buffers, each guarded by an event recorded after
-        its H2D copy: with track(sync=False) the host may run ahead of the device, and a staging
-        buffer is only rewritten once the copy that last read it has finished.  The device-side frame
-        buffer is also double-buffered: the crop kernel of step f may still be reading it when the
-        copy of step f+1 is queued on the same stream -- stream order covers that, the two slots
-        simply keep a host thread that uploads from a side stream safe too."""
+        """Host frames are copied straight from the caller's array into one of two device frame buffers with ONE blocking copy
+        (the runtime stages pageable memory itself: 53 GB/s for a 236 MB batch, ~20 us for one 230 KB frame; an explicit
+        pinned staging buffer filled by the CPU and DMA-ed from measured 6.7 GB/s and 2 ms -- tools/upload_probe.py).  The
+        copy returns when the caller's array has been read, so there is no staging buffer a later call could overwrite; it is
+        queued behind the previous step on the stream, whose kernels may still be reading the OTHER device buffer."""
         import torch
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
             t = frames
@@ -89,17 +84,9 @@ class BatchedVitTracker:
             if self.frames is None or tuple(self.frames[0].shape) != a.shape:
                 torch.cuda.current_stream().synchronize()      # nothing may still read the old buffers
                 self.frames = [torch.empty(a.shape, dtype=torch.uint8, device="cuda") for _ in range(2)]
-                self._pinned = [torch.empty(a.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-                self._h2d_done = [None, None]
             k = self._slot
             self._slot ^= 1
-            if self._h2d_done[k] is not None:
-                self._h2d_done[k].synchronize()                # the copy that last read this staging buffer
-            self._pinned[k].copy_(torch.from_numpy(a))
-            self.frames[k].copy_(self._pinned[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._h2d_done[k] = ev
+            self.frames[k].copy_(torch.from_numpy(a))
             t = self.frames[k]
         self.hw = (int(t.shape[1]), int(t.shape[2]))
         return t
@@ -137,10 +124,11 @@ class BatchedVitTracker:
         if self.frames is not None and any(fr.data_ptr() == f.data_ptr() for f in self.frames):
             # host frames land in one of two fixed device slots: the whole step (crop -> forward -> state update) is one
             # captured graph per slot -- one launch instead of three, no launch gaps inside the step
-            g, boxes, conf, _ = self._chunk_graph(fr.unsqueeze(0))
+            g, boxes, conf, keep = self._chunk_graph(fr.unsqueeze(0))
             g.replay()
             if sync:
-                return {"target_bbox": boxes[0].cpu(), "confidence": conf[0].cpu()}
+                hb, hc = self._read_back(boxes, conf, keep[1])
+                return {"target_bbox": hb[0], "confidence": hc[0]}
             return {"target_bbox": boxes[0], "confidence": conf[0]}
         # a caller-owned device tensor (a new address every call would mean a new capture every call): eager launches
         self.nat.crop(fr, self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
@@ -165,6 +153,7 @@ class BatchedVitTracker:
             self._chunk_graphs.pop(next(iter(self._chunk_graphs)))
         boxes = torch.empty(n, self.B, 4, dtype=torch.float64, device="cuda")
         conf = torch.empty(n, self.B, device="cuda")
+        host = (torch.empty(n, self.B, 4, dtype=torch.float64).pin_memory(), torch.empty(n, self.B).pin_memory())
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -178,7 +167,7 @@ class BatchedVitTracker:
                 boxes[i].copy_(self.states)
                 conf[i].copy_(self.out.conf)
         torch.cuda.current_stream().wait_stream(side)
-        self._chunk_graphs[key] = (g, boxes, conf, buf)       # buf: the graph's kernels read it, keep it alive
+        self._chunk_graphs[key] = (g, boxes, conf, (buf, host))   # buf: the graph's kernels read it, keep it alive; host: read-back
         return self._chunk_graphs[key]
 
     def track_chunk(self, frames, sync: bool = True):
@@ -201,20 +190,24 @@ class BatchedVitTracker:
             if self._chunk_buf is None or tuple(self._chunk_buf.shape) != a.shape:
                 torch.cuda.current_stream().synchronize()
                 self._chunk_buf = torch.empty(a.shape, dtype=torch.uint8, device="cuda")
-                self._chunk_pinned = torch.empty(a.shape, dtype=torch.uint8).pin_memory()
-                self._chunk_h2d = None
-            if self._chunk_h2d is not None:
-                self._chunk_h2d.synchronize()                 # the copy that last read the staging buffer
-            self._chunk_pinned.copy_(torch.from_numpy(a))
-            self._chunk_buf.copy_(self._chunk_pinned, non_blocking=True)
-            self._chunk_h2d = torch.cuda.Event()
-            self._chunk_h2d.record()
+            self._chunk_buf.copy_(torch.from_numpy(a))        # one blocking copy from the caller's array (see _upload)
             buf = self._chunk_buf
         n = int(buf.shape[0])
         self.hw = (int(buf.shape[2]), int(buf.shape[3]))
-        g, boxes, conf, _ = self._chunk_graph(buf)
+        g, boxes, conf, keep = self._chunk_graph(buf)
         g.replay()
         self.frame_id += n
         if sync:
-            return {"target_bbox": boxes.cpu(), "confidence": conf.cpu()}
+            hb, hc = self._read_back(boxes, conf, keep[1])
+            return {"target_bbox": hb, "confidence": hc}
         return {"target_bbox": boxes, "confidence": conf}
+
+    @staticmethod
+    def _read_back(boxes, conf, host):
+        """Device records -> pinned host tensors with two async copies and one stream synchronisation (a `.cpu()` per tensor
+        goes through pageable memory and synchronises twice); the caller gets its own copies."""
+        import torch
+        host[0].copy_(boxes, non_blocking=True)
+        host[1].copy_(conf, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return host[0].clone(), host[1].clone()

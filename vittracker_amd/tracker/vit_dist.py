@@ -3,10 +3,13 @@
 device step on the MI355X-native library.
 
 Differences from the reference that a caller can observe (all deliberate):
-  * the device step is ONE hipGraph replay on static buffers and ONE device->host copy of five
-    floats (windowed box + confidence); the reference launches ~130 kernels and syncs in
-    ``.tolist()`` (:108-109) while leaving ``confidence`` as a 0-d device tensor (:148).  Here
-    ``confidence`` is a Python float.
+  * by default the WHOLE frame step runs on the device: the uint8 frame is uploaded, ``vt_crop`` does ``sample_target`` +
+    ``Preprocessor.process`` (bit-identical to the host statement in ``host_ops``), the network replays as a graph and
+    ``vt_update_state`` does the map-back / clip; one device->host copy of the new state and the confidence ends the frame
+    (the lock-step ``BatchedVitTracker`` with one sequence).  ``params.host_crop = True`` keeps the reference's structure --
+    crop and pre-processing on the host (a numpy statement of cv2's resize: ~30 frames/s), ONE graph replay, five floats back.
+    The reference launches ~130 kernels and syncs in ``.tolist()`` (:108-109) while leaving ``confidence`` as a 0-d device
+    tensor (:148); here ``confidence`` is a Python float.
   * ``box_mask_z`` (``generate_mask_cond``, :62-66) is not computed: ``OstrackDist.forward``
     never consumes it, and the reference's helper raises NotImplementedError for template
     feature sizes other than 8/12/7/14 (``lib/utils/ce_utils.py:22-32``), i.e. for G128.
@@ -38,10 +41,39 @@ class BaseTracker:
         raise NotImplementedError
 
 
+_PIPELINES: dict = {}      # (checkpoint, sizes, factors) -> free BatchedVitTracker(B = 1) objects of this process
+
+
 class Vit_dist(BaseTracker):
     def __init__(self, params, dataset_name):
         super().__init__(params)
         import torch
+        self.cfg = params.cfg
+        self.preprocessor = Preprocessor()
+        self.state = None
+        self.feat_sz = self.cfg.TEST.SEARCH_SIZE // self.cfg.MODEL.BACKBONE.STRIDE
+        self.debug = getattr(params, "debug", 0)
+        self.frame_id = 0
+        self.save_all_boxes = params.save_all_boxes
+        self.z_dict1 = {}
+        self._bt = None
+        if not getattr(params, "host_crop", False):
+            from ..batched import BatchedVitTracker
+            # The harness makes a new tracker object per sequence (lib/test/evaluation/tracker.py:90-104); the device pipeline --
+            # weights, workspaces, captured graphs -- goes back to a per-process pool when its tracker object dies and is handed
+            # to the next one (initialize() resets all per-sequence state); objects alive at the same time get their own.
+            key = (getattr(params, "checkpoint", None), bool(getattr(params, "allow_synthetic_weights", False)),
+                   params.template_size, params.search_size, float(params.template_factor), float(params.search_factor),
+                   getattr(params, "yaml_name", None))
+            pool = _PIPELINES.setdefault(key, [])
+            bt = pool.pop() if pool else BatchedVitTracker(params, 1)   # builds the network, loads the checkpoint, sets the Hann window
+            bt.params = params
+            self._bt = bt
+            import weakref
+            weakref.finalize(self, pool.append, bt)          # back to the pool when this tracker object goes away
+            self.network = self._bt.net
+            self.output_window = hann2d(torch.tensor([self.feat_sz, self.feat_sz]).long(), centered=True).cuda()
+            return
         network = build_ostrack_dist(params.cfg)
         ckpt_path = getattr(params, "checkpoint", None)
         if ckpt_path and os.path.isfile(ckpt_path):
@@ -51,23 +83,13 @@ class Vit_dist(BaseTracker):
                 f"checkpoint {ckpt_path!r} not found (the reference fails in torch.load at "
                 f"lib/test/tracker/vit_dist.py:25); set params.allow_synthetic_weights=True to run on the "
                 f"seeded synthetic weights")
-        self.cfg = params.cfg
         self.network = network.cuda()
         self.network.eval()
-        self.preprocessor = Preprocessor()
-        self.state = None
-
-        self.feat_sz = self.cfg.TEST.SEARCH_SIZE // self.cfg.MODEL.BACKBONE.STRIDE
         # motion constraint (:34); the same values drive the fused device-side decode
         self.output_window = hann2d(torch.tensor([self.feat_sz, self.feat_sz]).long(), centered=True).cuda()
         nat = self.network._native()
         check_params_geometry(params, nat)
         nat.set_window(self.output_window.cpu().numpy())
-
-        self.debug = getattr(params, "debug", 0)
-        self.frame_id = 0
-        self.save_all_boxes = params.save_all_boxes
-        self.z_dict1 = {}
 
         # static device buffers + captured graph of the whole device step
         tz, tx = self.params.template_size, self.params.search_size
@@ -78,6 +100,14 @@ class Vit_dist(BaseTracker):
         self._rec_host = torch.empty(5).pin_memory()
 
     def initialize(self, image, info: dict):
+        if self._bt is not None:
+            self._bt.initialize(image[None], [list(info["init_bbox"])])
+            self.box_mask_z = None
+            self.state = info["init_bbox"]
+            self.frame_id = 0
+            if self.save_all_boxes:
+                return {"all_boxes": info["init_bbox"] * 1}
+            return None
         z_patch_arr, resize_factor, z_amask_arr = sample_target(image, info["init_bbox"], self.params.template_factor,
                                                                 output_sz=self.params.template_size)
         self.z_patch_arr = z_patch_arr
@@ -94,6 +124,12 @@ class Vit_dist(BaseTracker):
         import torch
         H, W, _ = image.shape
         self.frame_id += 1
+        if self._bt is not None:
+            out = self._bt.track(image[None])                # sync=True: state and confidence on the host
+            self.state = out["target_bbox"][0].tolist()
+            if self.save_all_boxes:
+                return {"target_bbox": self.state, "all_boxes": list(self.state)}
+            return {"target_bbox": self.state, "confidence": float(out["confidence"][0])}
         x_patch_arr, resize_factor, x_amask_arr = sample_target(image, self.state, self.params.search_factor,
                                                                 output_sz=self.params.search_size)
         search = self.preprocessor.process(x_patch_arr, x_amask_arr)
