@@ -40,14 +40,15 @@ print("OK", worst)
 
 VARIANTS = {
     # the fixtures' batches are small: by default they run the multi-workgroup forms, so the large-batch forms are forced here
-    "large_batch_forms_forced": {"VT_STEM_FUSED": "1", "VT_STEM_PIPE": "1", "VT_HEAD_FUSED": "1"},
+    "large_batch_forms_forced": {"VT_STEM_FUSED": "1", "VT_STEM_PIPE": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
+    "tile_parallel_blocks_forced": {"VT_BLOCKS_TILE": "1"},
     "two_kernel_stem": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0"},
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},
     "per_tower_head": {"VT_HEAD_FUSED": "0"},
-    "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1"},
-    "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0"},
-    "everything_off": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0", "VT_STEM_PIPE": "0", "VT_HEAD_FUSED": "0", "VT_BLOCKS_BAL": "0"},
+    "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1", "VT_BLOCKS_TILE": "0"},
+    "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0", "VT_BLOCKS_TILE": "0"},
+    "everything_off": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0", "VT_STEM_PIPE": "0", "VT_HEAD_FUSED": "0", "VT_BLOCKS_BAL": "0", "VT_BLOCKS_TILE": "0"},
 }
 
 

@@ -8,14 +8,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import bench
     geom = sys.argv[2]
     out = {}
-    for B in (96, 128, 160, 192, 224):
+    for B in [int(v) for v in os.environ.get("SWEEP_B", "96,128,160,192,224").split(",")]:
         r = bench.Runner(geom, B)
         out[B] = round(r.time_us(lambda: r.graph.launch(r.stream), 300, warm=50), 2)
         r.close()
     print(json.dumps(out))
     sys.exit(0)
 for geom in ("G128", "G256"):
-    for env in ({}, {"VT_STEM_FUSED": "0", "VT_STEM_PIPE": "0"}, {"VT_HEAD_FUSED": "0"}):
+    envs = ({}, {"VT_STEM_FUSED": "0", "VT_STEM_PIPE": "0"}, {"VT_HEAD_FUSED": "0"})
+    if os.environ.get("SWEEP_TILE"):      # the tile-parallel blocks form against the one-workgroup-per-frame form
+        envs = ({"VT_BLOCKS_TILE": "0"}, {"VT_BLOCKS_TILE": "1"})
+    for env in envs:
         e = dict(os.environ, **env)
         p = subprocess.run([sys.executable, __file__, "child", geom], env=e, capture_output=True, text=True)
         print(geom, env, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:])

@@ -17,6 +17,7 @@
 
 #include "vb_api.h"
 #include "vt_blocks.h"
+#include "vt_blocks_tile.h"
 #include "vt_head.h"
 #include "vt_stem.h"
 #include "vt_stem_fused.h"
@@ -73,6 +74,10 @@ struct vt_model {
     DevBuf act_x, act_z;             // layer-2 activations, NHWC(12)
     DevBuf tokens, feat;
     DevBuf tokens_c;                 // token matrix of the cached-template step: its template rows are written by vt_set_template only
+    // small batches (vt_blocks_tile.h): q / K image / V^T image of every tile and the residual stream between the per-block launches
+    DevBuf tile_q, tile_k, tile_v, tile_x;
+    int tile_frames = 0;             // frames those workspaces are sized for
+    int blocks_tile = -1;            // 1 / 0 force the tile-parallel form of the blocks / forbid it, -1 (default): by batch size
     DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
     int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
     DevBuf score, size, offset, pred, hann, conf;
@@ -346,9 +351,41 @@ int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int n
     return VT_OK;
 }
 
+// Small batches: one wave per (tile, frame), two launches per block (vt_blocks_tile.h).
+template <int NT>
+int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zc) {
+    f4* const qb = reinterpret_cast<f4*>(m->tile_q.p);
+    f4* const kb = reinterpret_cast<f4*>(m->tile_k.p);
+    f4* const vb = reinterpret_cast<f4*>(m->tile_v.p);
+    const float* const normP = m->blocks.p + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;      // norm.weight, norm.bias
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const float* P = m->blocks.p + (size_t)blk * vtb::BLOCK_STRIDE;
+        const float* xin = blk == 0 ? tokens : m->tile_x.p;
+        const bool last = blk == nblocks - 1;
+        const int skip_z = (blk == m->cfg.depth - 1 && resid == nullptr) ? 1 : 0;
+        hipLaunchKernelGGL((vtb::tile_qkv_kernel<NT>), dim3(NT, B), dim3(64), 0, st, xin, P, qb, kb, vb, m->zcache.p,
+                           blk == 0 ? zc : 0, m->len_z);
+        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(64), 0, st, xin, m->tile_x.p, P, qb, kb, vb,
+                           last ? normP : nullptr, feat, last ? resid : nullptr, m->len_z, skip_z);
+    }
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
 int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid, int zc = 0) {
     // zc: template cache mode of block 0 (0 off, 1 store, 2 load)
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
+    // Kernel form by batch size: with few frames a workgroup per frame leaves most of the chip idle (a frame's latency is one
+    // CU's worth of MFMA issue); one wave per tile spreads frames x tiles over the SIMDs instead.
+    const int NTr = m->L / 16;
+    const bool diag = m->dbg_skip_tile != -1 || m->dbg_stamps != nullptr;
+    // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 280 -> 142, B=32 301 -> 185,
+    // B=64 315 -> 228, B=96 357 -> 283, B=128 372 -> 374; G128 (5 tiles: a 47 us frame kernel against six small launches)
+    // B=1 81 -> 87: never by default
+    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 && B <= 96) : m->blocks_tile != 0;
+    if (want_tile && !diag && nblocks >= 1 && B <= m->tile_frames && (NTr == 5 || NTr == 20))
+        return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc)
+                        : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc);
     switch (m->L / 16) {
         case 5:
             if (m->blocks_bal) return zc ? launch_blocks<5, 8, 1, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
@@ -566,6 +603,11 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->feat, B * m->len_x * 48);
     A(m->tokens_c, B * m->L * 48);
     A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
+    m->tile_frames = (int)std::min<size_t>(B, 128);
+    A(m->tile_q, (size_t)m->tile_frames * m->L * 48);
+    A(m->tile_k, (size_t)m->tile_frames * m->L * 48);
+    A(m->tile_v, (size_t)m->tile_frames * m->L * 48);
+    A(m->tile_x, (size_t)m->tile_frames * m->L * 48);
     A(m->score, B * m->len_x);
     A(m->size, B * 2 * m->len_x);
     A(m->offset, B * 2 * m->len_x);
@@ -583,6 +625,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->stem_fused = env_int("VT_STEM_FUSED", -1);
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
     m->head_fused = env_int("VT_HEAD_FUSED", -1);
+    m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
@@ -662,6 +705,7 @@ void vt_destroy(vt_model* m) {
     m->stem_w2k.release();
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
+                     &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
