@@ -365,7 +365,7 @@ int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, 
         const int skip_z = (blk == m->cfg.depth - 1 && resid == nullptr) ? 1 : 0;
         hipLaunchKernelGGL((vtb::tile_qkv_kernel<NT>), dim3(NT, B), dim3(64), 0, st, xin, P, qb, kb, vb, m->zcache.p,
                            blk == 0 ? zc : 0, m->len_z);
-        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(64), 0, st, xin, m->tile_x.p, P, qb, kb, vb,
+        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(256), 0, st, xin, m->tile_x.p, P, qb, kb, vb,
                            last ? normP : nullptr, feat, last ? resid : nullptr, m->len_z, skip_z);
     }
     HIP_TRY(hipGetLastError());
@@ -379,10 +379,9 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     // CU's worth of MFMA issue); one wave per tile spreads frames x tiles over the SIMDs instead.
     const int NTr = m->L / 16;
     const bool diag = m->dbg_skip_tile != -1 || m->dbg_stamps != nullptr;
-    // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 280 -> 142, B=32 301 -> 185,
-    // B=64 315 -> 228, B=96 357 -> 283, B=128 372 -> 374; G128 (5 tiles: a 47 us frame kernel against six small launches)
-    // B=1 81 -> 87: never by default
-    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 && B <= 96) : m->blocks_tile != 0;
+    // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 92, B=32 300 -> 146,
+    // B=64 314 -> 192, B=128 371 -> 323; G128 B=1 81 -> 67, B=32 83 -> 72, B=48 84 -> 81, B=64 85 -> 90
+    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 40) : m->blocks_tile != 0;
     if (want_tile && !diag && nblocks >= 1 && B <= m->tile_frames && (NTr == 5 || NTr == 20))
         return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc)
                         : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc);
