@@ -354,19 +354,22 @@ int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int n
 // Small batches: one wave per (tile, frame), two launches per block (vt_blocks_tile.h).
 template <int NT>
 int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zc) {
+    // two workspace sets: a block reads q / K / V^T from one while its workgroups write the next block's into the other
+    const size_t set = (size_t)m->tile_frames * m->L * 48 / 4;                  // float4 per set
     f4* const qb = reinterpret_cast<f4*>(m->tile_q.p);
     f4* const kb = reinterpret_cast<f4*>(m->tile_k.p);
     f4* const vb = reinterpret_cast<f4*>(m->tile_v.p);
     const float* const normP = m->blocks.p + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;      // norm.weight, norm.bias
+    hipLaunchKernelGGL((vtb::tile_qkv_kernel<NT>), dim3(NT, B), dim3(64), 0, st, tokens, m->blocks.p, qb, kb, vb, m->zcache.p, zc, m->len_z);
     for (int blk = 0; blk < nblocks; ++blk) {
         const float* P = m->blocks.p + (size_t)blk * vtb::BLOCK_STRIDE;
         const float* xin = blk == 0 ? tokens : m->tile_x.p;
         const bool last = blk == nblocks - 1;
         const int skip_z = (blk == m->cfg.depth - 1 && resid == nullptr) ? 1 : 0;
-        hipLaunchKernelGGL((vtb::tile_qkv_kernel<NT>), dim3(NT, B), dim3(64), 0, st, xin, P, qb, kb, vb, m->zcache.p,
-                           blk == 0 ? zc : 0, m->len_z);
-        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(256), 0, st, xin, m->tile_x.p, P, qb, kb, vb,
-                           last ? normP : nullptr, feat, last ? resid : nullptr, m->len_z, skip_z);
+        const size_t cur = (size_t)(blk & 1) * set, nxt = (size_t)((blk & 1) ^ 1) * set;
+        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(256), 0, st, xin, m->tile_x.p, P, qb + cur, kb + cur, vb + cur,
+                           last ? normP : nullptr, feat, last ? resid : nullptr, m->len_z, skip_z,
+                           last ? nullptr : P + vtb::BLOCK_STRIDE, qb + nxt, kb + nxt, vb + nxt);
     }
     HIP_TRY(hipGetLastError());
     return VT_OK;
@@ -379,9 +382,9 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     // CU's worth of MFMA issue); one wave per tile spreads frames x tiles over the SIMDs instead.
     const int NTr = m->L / 16;
     const bool diag = m->dbg_skip_tile != -1 || m->dbg_stamps != nullptr;
-    // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 92, B=32 300 -> 146,
-    // B=64 314 -> 192, B=128 371 -> 323; G128 B=1 81 -> 67, B=32 83 -> 72, B=48 84 -> 81, B=64 85 -> 90
-    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 40) : m->blocks_tile != 0;
+    // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 86, B=32 300 -> 136,
+    // B=64 314 -> 183, B=128 371 -> 315; G128 B=1 81 -> 64, B=32 83 -> 70, B=64 85 -> 83, B=128 96 -> 103
+    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 64) : m->blocks_tile != 0;
     if (want_tile && !diag && nblocks >= 1 && B <= m->tile_frames && (NTr == 5 || NTr == 20))
         return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc)
                         : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc);
@@ -603,9 +606,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->tokens_c, B * m->L * 48);
     A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
     m->tile_frames = (int)std::min<size_t>(B, 128);
-    A(m->tile_q, (size_t)m->tile_frames * m->L * 48);
-    A(m->tile_k, (size_t)m->tile_frames * m->L * 48);
-    A(m->tile_v, (size_t)m->tile_frames * m->L * 48);
+    A(m->tile_q, 2 * (size_t)m->tile_frames * m->L * 48);      // two sets each (launch_blocks_tile)
+    A(m->tile_k, 2 * (size_t)m->tile_frames * m->L * 48);
+    A(m->tile_v, 2 * (size_t)m->tile_frames * m->L * 48);
     A(m->tile_x, (size_t)m->tile_frames * m->L * 48);
     A(m->score, B * m->len_x);
     A(m->size, B * 2 * m->len_x);

@@ -2,10 +2,11 @@
 //
 // blocks_kernel (vt_blocks.h) gives a frame one workgroup on one CU: its latency is a CU's worth of MFMA issue per frame
 // (G256: 243 us) however few frames there are -- a B = 1 client (the reference harness's tracker plugin) leaves 255 CUs idle.
-// Here a block is two launches over (tile, frame) workgroups:
-//     tile_qkv_kernel       (1 wave)  LayerNorm-1 + qkv of the tile -> q, K image, V^T image in a global workspace
+// Here the stack is 1 + depth launches over (tile, frame) workgroups:
+//     tile_qkv_kernel       (1 wave)  block 0's LayerNorm-1 + qkv of the tile -> q, K image, V^T image in a global workspace
 //     tile_attn_mlp_kernel  (4 waves) softmax(q K^T) V + proj + residual, LayerNorm-2 + MLP + residual of the tile (all keys
-//                           from the workspace, L2-resident), the final LayerNorm after the last block
+//                           from the workspace, L2-resident); then the NEXT block's LayerNorm-1 + qkv of the tile into the
+//                           other workspace set (per-token work), or the final LayerNorm after the last block
 // The kernel boundary is the only synchronisation (K / V of every tile must exist before any tile attends).  Same arithmetic and
 // operand images as blocks_kernel (the four-way split of a tile is its guest waves' split); weights and the small parameters
 // come straight from L2.  Used when frames x tiles is well below what fills the chip (vittrack.hip::run_blocks): G256 B = 1
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
                                                           const float* __restrict__ P, const f4* __restrict__ qb,
                                                           const f4* __restrict__ kb, const f4* __restrict__ vb,
                                                           const float* __restrict__ normP, float* __restrict__ feat,
-                                                          float* __restrict__ resid, int len_z, int skip_z) {
+                                                          float* __restrict__ resid, int len_z, int skip_z,
+                                                          const float* __restrict__ Pn,      // next block's parameters, or null
+                                                          f4* __restrict__ qn, f4* __restrict__ kn, f4* __restrict__ vn) {
     constexpr int L = NT * 16;
     constexpr float SCALE_LOG2E = 0.14433756729740643f * 1.4426950408889634f;
     __shared__ f4 Pg[4 * NC * 64];        // partial P.V / partial fc2 outputs of the four waves
@@ -224,30 +227,61 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         for (int ot = 0; ot < NC; ++ot) Pg[(g * NC + ot) * 64 + lane] = part[ot];
     }
     __syncthreads();
-    if (g != 0) return;                                  // one wave finishes the tile
 #pragma unroll
-    for (int ot = 0; ot < NC; ++ot) {
+    for (int ot = 0; ot < NC; ++ot) {                    // every wave: the tile's residual stream after this block
         x[ot] = x[ot] + ld4(P + O_B2 + 16 * ot + 4 * q);
 #pragma unroll
         for (int k = 0; k < 4; ++k) x[ot] = x[ot] + Pg[(k * NC + ot) * 64 + lane];
     }
-    {
+    if (g == 0) {
         float* dst = xout + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
 #pragma unroll
         for (int c = 0; c < NC; ++c) st4(dst + 16 * c, x[c]);
-    }
-    if (normP != nullptr) {
-        if (resid != nullptr) {
-            float* dst = resid + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
+        if (normP != nullptr) {
+            if (resid != nullptr) {
+                float* rd = resid + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) st4(dst + 16 * c, x[c]);
+                for (int c = 0; c < NC; ++c) st4(rd + 16 * c, x[c]);
+            }
+            if (16 * T >= len_z) {
+                f4 h[NC];
+                layer_norm_img(x, h, normP, normP + C, q);
+                float* fd = feat + ((size_t)b * (L - len_z) + (16 * T - len_z) + tok) * C + 4 * q;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) st4(fd + 16 * c, h[c]);
+            }
         }
-        if (16 * T >= len_z) {
-            f4 h[NC];
-            layer_norm_img(x, h, normP, normP + C, q);
-            float* dst = feat + ((size_t)b * (L - len_z) + (16 * T - len_z) + tok) * C + 4 * q;
+    }
+    // ---- the NEXT block's LayerNorm-1 + qkv of this tile (per-token work: it needs nothing from the other tiles), into the other
+    // workspace set -- the tile_qkv launch of blocks 1.. disappears.  Wave 0: q, wave 1: k, wave 2: v^T, the chains of tile_qkv_kernel.
+    if (Pn != nullptr && g < 3) {
+        f4 h[NC];
+        layer_norm_img(x, h, Pn + O_LN1G, Pn + O_LN1B, q);
+        f4 acc[NC];
+        if (g < 2) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) st4(dst + 16 * c, h[c]);
+            for (int ot = 0; ot < NC; ++ot) acc[ot] = ld4(Pn + O_BQKV + 16 * (g * NC + ot) + 4 * q);
+            gemm_stage<NC, NC, true, false>(
+                [&](int c, f4 (&a)[NC]) {
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(Pn + O_WQKV, (g * NC + ot) * NC + c, lane);
+                },
+                [&](int c) { return h[c]; }, acc);
+            f4* dst = (g == 0 ? qn : kn) + ((size_t)b * NT + T) * NC * 64 + lane;
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot) dst[ot * 64] = acc[ot];
+        } else {
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(Pn[O_BQKV + 2 * C + 16 * ot + tok]);
+            gemm_stage<NC, NC, false, false>(
+                [&](int c, f4 (&bw)[NC]) {
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) bw[ot] = wimg(Pn + O_WQKV, (2 * NC + ot) * NC + c, lane);
+                },
+                [&](int c) { return h[c]; }, acc);
+            f4* dst = vn + (size_t)b * NC * NT * 64 + (size_t)T * 64 + lane;
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot) dst[(size_t)ot * NT * 64] = acc[ot];
         }
     }
 }
