@@ -254,7 +254,11 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
     float* const act_z = m->act_z.p + f0 * (size_t)(Tz / 4) * (Tz / 4) * 12;
-    const StemPlan px{m->plan_r2[0], m->plan_r4[0]}, pz{m->plan_r2[1], m->plan_r4[1]};
+    StemPlan px{m->plan_r2[0], m->plan_r4[0]};
+    const StemPlan pz{m->plan_r2[1], m->plan_r4[1]};
+    // small batches of the 128-px search crop: stem_b in bands of 2 token rows (4 workgroups per crop instead of 2) shortens the
+    // latency chain of a band (B=1 step 63.5 -> 59.9 us); at large batches the halo rows it recomputes cost more than that
+    if (Tx == 128 && B <= 80 && px.r4 == 4 && !std::getenv("VT_STEM_R4_128")) px.r4 = 2;
     for (const auto& pr : {std::make_pair(Tx, px), std::make_pair(Tz, pz)}) {
         const int T = pr.first, r2 = pr.second.r2, r4 = pr.second.r4;
         const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
@@ -383,8 +387,8 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     const int NTr = m->L / 16;
     const bool diag = m->dbg_skip_tile != -1 || m->dbg_stamps != nullptr;
     // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 86, B=32 300 -> 136,
-    // B=64 314 -> 183, B=128 371 -> 315; G128 B=1 81 -> 64, B=32 83 -> 70, B=64 85 -> 83, B=128 96 -> 103
-    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 64) : m->blocks_tile != 0;
+    // B=64 314 -> 183, B=128 371 -> 315; G128 B=1 78 -> 59, B=16 79 -> 62, B=64 84 -> 83, B=80 88 -> 86, B=96 95 -> 95
+    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 80) : m->blocks_tile != 0;
     if (want_tile && !diag && nblocks >= 1 && B <= m->tile_frames && (NTr == 5 || NTr == 20))
         return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc)
                         : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc);
