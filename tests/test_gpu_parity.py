@@ -256,3 +256,32 @@ def test_multi_step_graph_equals_eager_steps(geom):
     m.close()
     with pytest.raises(native.VtError, match="closed or re-sized"):
         g.launch()
+
+
+@pytest.mark.parametrize("geom,B", [("G128", 64), ("G256", 96)])
+def test_small_batch_forms_are_batch_invariant(geom, B):
+    """Default switches at batches that run the small-batch forms (blocks as (tile, frame) workgroups, multi-workgroup stem and
+    head): frame i of the batch equals the same frame run alone, and a permuted batch permutes the outputs -- bit for bit
+    (workgroups never touch another frame's data, and the kernel form is the same for 1 and for B frames)."""
+    from vittracker_amd import synth
+    torch = _torch()
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    z, x = synth.synth_inputs(21, B, tz, tx)
+    m = _model(sd, geom, B)
+    zd, xd = _dev(z), _dev(x)
+    big = m.forward(zd, xd)
+    perm = torch.randperm(B, device="cuda")
+    pm = m.forward(zd[perm].contiguous(), xd[perm].contiguous())
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+        assert torch.equal(getattr(big, k)[perm], getattr(pm, k)), k
+    for i in (0, B // 2, B - 1):
+        one = m.forward(zd[i:i + 1].contiguous(), xd[i:i + 1].contiguous())
+        assert torch.equal(one.score_map[0], big.score_map[i])
+        assert torch.equal(one.hann_boxes[0], big.hann_boxes[i])
+    # and a stage call that stops after two blocks returns the residual stream of the tile form (template tiles included)
+    tok = m.stem(zd[:3].contiguous(), xd[:3].contiguous())
+    feat2, resid2 = m.blocks(tok, nblocks=2, want_resid=True)
+    feat3, resid3 = m.blocks(tok, nblocks=3, want_resid=True)
+    assert torch.isfinite(resid2).all() and torch.isfinite(resid3).all() and not torch.equal(resid2, resid3)
+    assert torch.equal(feat3, m.blocks(tok))      # without the residual output the last block skips the template tiles: same features
