@@ -285,3 +285,33 @@ def test_small_batch_forms_are_batch_invariant(geom, B):
     feat3, resid3 = m.blocks(tok, nblocks=3, want_resid=True)
     assert torch.isfinite(resid2).all() and torch.isfinite(resid3).all() and not torch.equal(resid2, resid3)
     assert torch.equal(feat3, m.blocks(tok))      # without the residual output the last block skips the template tiles: same features
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_decode_sees_the_maps_of_its_own_step(geom):
+    """Small batches: the towers of a frame are three workgroups (possibly on different XCDs) and the decode reads the maps they
+    wrote.  With fresh inputs every step, the boxes must equal cal_bbox on the maps of the SAME step -- a stale read of a previous
+    step's maps would show here.  (Written for a variant in which the last tower workgroup to finish decoded in-kernel behind an
+    agent-scope fence; that variant passed but measured slower than the separate decode launch -- DESIGN.md section 9.)"""
+    from vittracker_amd import synth
+    torch = _torch()
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    B = 5
+    m = _model(sd, geom, B)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    z = torch.randn(B, 3, tz, tz, device="cuda", generator=g)
+    xs = [torch.randn(B, 3, tx, tx, device="cuda", generator=g) for _ in range(4)]
+    graph, gout = m.capture(z, xs[0])
+    for it in range(120):
+        x = xs[it & 3]
+        x.mul_(1.0 + 0.01 * ((it % 7) - 3))                 # the inputs keep changing
+        if it % 3 == 0 and x is xs[0]:
+            graph.launch()
+            out = gout
+        else:
+            out = m.forward(z, x)
+        torch.cuda.synchronize()
+        bbox, mx = m.cal_bbox(out.score_map, out.size_map, out.offset_map)
+        assert torch.equal(bbox.view(B, 4), out.pred_boxes.view(B, 4)), it
+        assert torch.equal(mx.view(B), out.conf.view(B)), it
