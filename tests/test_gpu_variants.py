@@ -45,7 +45,8 @@ VARIANTS = {
     "two_kernel_stem": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0"},
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},
-    "per_tower_head": {"VT_HEAD_FUSED": "0"},
+    "per_tower_head": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "0"},
+    "g256_head_conv1_split_forced": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "1"},
     "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1", "VT_BLOCKS_TILE": "0"},
     "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0", "VT_BLOCKS_TILE": "0"},
     "everything_off": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0", "VT_STEM_PIPE": "0", "VT_HEAD_FUSED": "0", "VT_BLOCKS_BAL": "0", "VT_BLOCKS_TILE": "0"},

@@ -16,7 +16,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 for geom in ("G128", "G256"):
     envs = ({}, {"VT_STEM_FUSED": "0", "VT_STEM_PIPE": "0"}, {"VT_HEAD_FUSED": "0"})
-    if os.environ.get("SWEEP_TILE"):      # the tile-parallel blocks form against the one-workgroup-per-frame form
+    if os.environ.get("SWEEP_HEAD"):      # F = 16 head: conv1 as its own launch over row strips against the per-tower form
+        envs = ({"VT_HEAD_SPLIT": "0"}, {"VT_HEAD_SPLIT": "1"})
+    elif os.environ.get("SWEEP_TILE"):      # the tile-parallel blocks form against the one-workgroup-per-frame form
         envs = ({"VT_BLOCKS_TILE": "0"}, {"VT_BLOCKS_TILE": "1"})
     for env in envs:
         e = dict(os.environ, **env)

@@ -76,6 +76,9 @@ struct vt_model {
     DevBuf tokens_c;                 // token matrix of the cached-template step: its template rows are written by vt_set_template only
     // small batches (vt_blocks_tile.h): q / K image / V^T image of every tile and the residual stream between the per-block launches
     DevBuf tile_q, tile_k, tile_v, tile_x;
+    DevBuf head_m1;                  // F = 16, small batches: conv1 output of the three towers, [frames][3][8][NPIX] float4, zero borders
+    int head_m1_frames = 0;
+    int head_split = -1;             // F = 16: conv1 as a launch of its own over row strips (1 / 0 force, -1: by batch size)
     int tile_frames = 0;             // frames those workspaces are sized for
     int blocks_tile = -1;            // 1 / 0 force the tile-parallel form of the blocks / forbid it, -1 (default): by batch size
     DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
@@ -413,6 +416,10 @@ int run_decode(vt_model* m, hipStream_t st, const float* score, const float* siz
     return VT_OK;
 }
 
+// F = 16: batches up to this size run conv1 as its own launch.  SWEEP_HEAD=1 tools/small_batch_sweep.py, us per step, per-tower
+// form -> split form: B=1 86.0 -> 78.6, B=8 96.6 -> 91.5, B=16 110.3 -> 103.5, B=32 135.2 -> 132.9, B=64 181.7 -> 186.2
+constexpr int HEAD_SPLIT_MAX_B = 32;
+
 int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o, size_t f0 = 0) {
     // outputs of the slice starting at frame f0 (feat already points at the slice)
     const size_t n = (size_t)m->len_x;
@@ -450,6 +457,12 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         else go(&vth::head_seq_kernel<16, 8, false>);
         HIP_TRY(hipGetLastError());
         return VT_OK;
+    } else if (m->F == 16 && !m->skip_head && B <= m->head_m1_frames && f0 == 0 &&
+               (m->head_split < 0 ? B <= HEAD_SPLIT_MAX_B : m->head_split != 0)) {
+        // small batches: conv1 of every tower over four row strips (12 workgroups per frame), then the rest of each tower
+        hipLaunchKernelGGL(vth::head_conv1_kernel<16>, dim3(4, 3, B), dim3(512), 0, st, feat, m->head.p, m->head_m1.p);
+        hipLaunchKernelGGL((vth::head_towers_kernel<16, 8, false, true>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES, st,
+                           m->head_m1.p, m->head.p, score, size, offset, 0);
     } else if (m->F == 16) {
         // 129 KB of LDS per tower = one workgroup per CU: 8 waves give every SIMD two instruction streams
         if (m->skip_head)
@@ -614,6 +627,11 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->tile_k, 2 * (size_t)m->tile_frames * m->L * 48);
     A(m->tile_v, 2 * (size_t)m->tile_frames * m->L * 48);
     A(m->tile_x, (size_t)m->tile_frames * m->L * 48);
+    if (m->F == 16) {
+        m->head_m1_frames = (int)std::min<size_t>(B, 176);
+        A(m->head_m1, (size_t)m->head_m1_frames * 3 * 8 * vth::Geo<16>::NPIX * 4);
+        if (!rc && hipMemset(m->head_m1.p, 0, m->head_m1.n * sizeof(float)) != hipSuccess) rc = fail(VT_ERR_HIP, "hipMemset(head_m1) failed");
+    }
     A(m->score, B * m->len_x);
     A(m->size, B * 2 * m->len_x);
     A(m->offset, B * 2 * m->len_x);
@@ -632,6 +650,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
     m->head_fused = env_int("VT_HEAD_FUSED", -1);
     m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
+    m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
@@ -692,6 +711,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_towers_kernel<16, 8, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vth::Geo<16>::LDS_BYTES));
         if (e != hipSuccess) rc = fail(VT_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -711,7 +733,7 @@ void vt_destroy(vt_model* m) {
     m->stem_w2k.release();
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
-                     &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x,
+                     &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);

@@ -165,7 +165,9 @@ struct HeadConv {
 
 // grid (B, 3): tower 0 = ctr, 1 = offset, 2 = size.   feat: (B, F*F, 48) normalised search tokens.
 // DIAG: diagnostic build (VT_SKIP_HEAD); production instantiations compile `skip` out.
-template <int F, int NW = 4, bool DIAG = false>
+// FROM_M1: conv1's output map comes from global memory (head_conv1_kernel ran it over several workgroups); `feat` then points at
+// that buffer, [B][3 towers][8 planes][NPIX] float4 with zero borders.
+template <int F, int NW = 4, bool DIAG = false, bool FROM_M1 = false>
 __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ hw,
                                                           float* __restrict__ score, float* __restrict__ size,
@@ -185,6 +187,15 @@ __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __res
     HeadConv<W1, 16, F, NW> c2;
     HeadConv<16, 8, F, NW> c3;
     HeadConv<8, 4, F, NW> c4;
+    if constexpr (FROM_M1) {
+        c2.prefetch(tw + O_W2, wave, lane);
+        // conv1's output (borders included: they are zero in the buffer) -> m1; clear m2 (its borders are read by conv3)
+        const f4* src = reinterpret_cast<const f4*>(feat) + ((size_t)b * 3 + t) * (W1 / 4) * G::NPIX;
+        for (int i = threadIdx.x; i < (W1 / 4) * G::NPIX; i += NW * 64) m1[i] = src[i];
+        for (int i = threadIdx.x; i < 4 * G::NPIX; i += NW * 64) m2[i] = splat4(0.f);
+        c3.prefetch(tw + O_W3, wave, lane);
+        __syncthreads();
+    } else {
     c1.prefetch(tw + O_W1, wave, lane);        // first weight burst flies during the map set-up
     if (!(skip & 1))
         for (int i = threadIdx.x; i < G::QUADS * G::NPIX; i += NW * 64) in_map[i] = splat4(0.f);
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(NW * 64) void head_towers_kernel(const float* __res
     if (!(skip & 4)) c1.run(in_map, m1, tw + O_W1, tw + O_B1, wave, lane);
     c3.prefetch(tw + O_W3, wave, lane);
     __syncthreads();
+    }
     if (!(skip & 8)) c2.run(m1, m2, tw + O_W2, tw + O_B2, wave, lane);
     c4.prefetch(tw + O_W4, wave, lane);
     __syncthreads();
@@ -383,6 +395,57 @@ __global__ __launch_bounds__(768) void head_fused_kernel(const float* __restrict
             if (conf != nullptr) conf[b] = v0;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ head_conv1 (small batches, F = 16)
+// With few frames a tower's conv1 (69 % of its MACs) on ONE workgroup is one CU's worth of MFMA issue (11.5 us) while the chip
+// idles.  Here it is a launch of its own over (4-row strip, tower, frame) workgroups of 8 waves -- wave = (output tile, row of
+// the strip), 108 MFMAs each -- on a 6-row slice of the input map; the ReLU'd result goes to a global buffer with zero borders
+// ([B][3][8 planes][NPIX] float4) that head_towers_kernel<..., FROM_M1> stages instead of running conv1.  Same chains as
+// HeadConv<C, W1, 16>::run: same results.
+template <int F>
+__global__ __launch_bounds__(512) void head_conv1_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                         float* __restrict__ m1g) {
+    using G = Geo<F>;
+    static_assert(F == 16 && !G::NOHALO, "written for the zero-bordered 16 x 16 layout");
+    constexpr int ROWS = 4, SR = ROWS + 2, NPL = ((SR * G::P + 15) / 16) * 16;       // strip: 4 rows + halo rows, 112 entries per plane
+    constexpr int NQ = C / 4, NCH = nchunks(C), MAXC = 9, NPASS = NCH / MAXC;
+    static_assert(NCH % MAXC == 0, "27 chunks in 3 passes");
+    __shared__ f4 strip[NQ * NPL];
+    const int sg = blockIdx.x, t = blockIdx.y, b = blockIdx.z;      // strip (rows 4 sg .. 4 sg + 3), tower, frame
+    const int lane = threadIdx.x & 63, q = lane >> 4, px = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ot = wave & 1, lrow = wave >> 1;                       // output tile, row inside the strip
+    const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
+    const float* __restrict__ wb = tw + O_W1 + (size_t)ot * NCH * 256;
+    f4 a[2][MAXC][1];
+    vtc::load_weights<1, MAXC, NCH>(wb, 0, MAXC, lane, a[0]);
+    for (int i = threadIdx.x; i < NQ * NPL; i += 512) strip[i] = splat4(0.f);
+    __syncthreads();
+    // rows 4 sg - 1 .. 4 sg + 4 of the frame's map (those inside the image), local row = row - (4 sg - 1)
+    for (int i = threadIdx.x; i < SR * F * NQ; i += 512) {
+        const int icq = i / (SR * F), r = (i / F) % SR, col = i % F, row = ROWS * sg - 1 + r;
+        if (row >= 0 && row < F)
+            strip[icq * NPL + r * G::P + col + 1] = ld4(feat + ((size_t)b * F * F + row * F + col) * C + 4 * icq);
+    }
+    __syncthreads();
+    int base[1] = {lrow * G::P + px};                                // tap (0,0) of this wave's row: one row up, one column left
+    f4 acc[1][1] = {{ld4(tw + O_B1 + 16 * ot + 4 * q)}};
+    auto off = [&](int c) {
+        int tap, icq;
+        vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        return icq * NPL + dy * G::P + dx;
+    };
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (p + 1 < NPASS) vtc::load_weights<1, MAXC, NCH>(wb, (p + 1) * MAXC, MAXC, lane, a[(p + 1) & 1]);
+        vtc::mma_pass<1, 1, MAXC, MAXC, true>(strip, base, a[p & 1], p * MAXC, off, acc);
+    }
+    f4 v = acc[0][0];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    f4* dst = reinterpret_cast<f4*>(m1g) + (((size_t)b * 3 + t) * (W1 / 4) + 4 * ot + q) * G::NPIX;
+    dst[G::interior(ROWS * sg + lrow, px)] = v;
 }
 
 // ------------------------------------------------------------------------------------------ head_seq
