@@ -316,3 +316,27 @@ def test_decode_sees_the_maps_of_its_own_step(geom):
         bbox, mx = m.cal_bbox(out.score_map, out.size_map, out.offset_map)
         assert torch.equal(bbox.view(B, 4), out.pred_boxes.view(B, 4)), it
         assert torch.equal(mx.view(B), out.conf.view(B)), it
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_forms_agree_at_the_switch_points(geom):
+    """Kernel forms switch with the batch size at 32 / 33 (G256 head), 80 / 81, 128 / 129 and 176 / 177: at every such batch a
+    frame's outputs agree with the same frame run alone (the B = 1 forms are held to the reference fixtures by the golden
+    tests) to fp32 noise."""
+    from vittracker_amd import synth
+    torch = _torch()
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    Bmax = 177
+    z, x = synth.synth_inputs(31, Bmax, tz, tx)
+    m = _model(sd, geom, Bmax)
+    zd, xd = _dev(z), _dev(x)
+    singles = {i: m.forward(zd[i:i + 1].contiguous(), xd[i:i + 1].contiguous()) for i in (0, 31, 79, 127, 175)}
+    for B in (32, 33, 80, 81, 128, 129, 176, 177):
+        out = m.forward(zd[:B].contiguous(), xd[:B].contiguous())
+        for i, one in singles.items():
+            if i < B:
+                for k in ("score_map", "size_map", "offset_map"):
+                    err = float((getattr(out, k)[i] - getattr(one, k)[0]).abs().max())
+                    assert err < 2e-5, (B, i, k, err)
+                assert float((out.hann_boxes[i] - one.hann_boxes[0]).abs().max()) < 1e-5, (B, i)

@@ -9,7 +9,7 @@ from vittracker_amd import native, synth
 
 bad = 0
 for geom, (tz, tx) in (("G128", (64, 128)), ("G256", (128, 256))):
-    for B in (1, 5, 64, 256):
+    for B in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("1", "5", "64", "256"))]:
         sd = synth.synth_state_dict(B, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
         m = native.Model(tz, tx, max_batch=B)
         m.load_state_dict(sd)
