@@ -27,14 +27,19 @@ def _model(geom, B, precision, seed=0):
     return m
 
 
+# The kernel form follows the batch size: B = 5 runs the small-batch forms (tile_qkv / tile_attn_mlp with zc, stem_a /
+# stem_b with zero bands); 81 / 129 / 177 cross every switch point (G128: tile form <= 80, stem_fused > 80, head_fused > 176; G256:
+# tile form <= 128, stem_pipe and head_seq > 176), so the large-batch cached kernels -- stem_fused_kernel<1|2>,
+# stem_pipe_kernel<.., 1|2>, blocks_kernel<..., ZC = true>, the ones the config-5 bench times and BatchedVitTracker runs -- are
+# compared with the uncached step too.
+@pytest.mark.parametrize("B", [5, 81, 129, 177])
 @pytest.mark.parametrize("precision", ["f32", "f16"])
 @pytest.mark.parametrize("geom", ["G128", "G256"])
-def test_template_cache_is_exact(geom, precision):
+def test_template_cache_is_exact(geom, precision, B):
     import torch
     from vittracker_amd import native, synth
     tz, tx = GEOMS[geom]
-    B = 5
-    m = _model(geom, 8, precision)
+    m = _model(geom, B + 3, precision)
     z, x = synth.synth_inputs(11, B, tz, tx)
     _, x2 = synth.synth_inputs(12, B, tz, tx)
     zd, xd, x2d = (torch.from_numpy(a).cuda() for a in (z, x, x2))

@@ -93,3 +93,22 @@ def test_bench_record_graph_form_on_one_gpu():
     assert r.returncode == 0, r.stdout + r.stderr
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["checked"] and j["value"] > 0 and j["config"]["steps_per_graph"] == 4 and j["steps"] == 11
+
+
+def test_record_graph_form_is_as_fast_as_the_plain_form():
+    """SCALE N = 1 must agree with BENCH: at the metric's batch the record-graph launch form (what every rank runs when N > 1)
+    and the plain form report the same frames/s (best of three alternating runs each, within 3 %)."""
+    import json
+    import subprocess
+    import sys
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "400", "--warmup", "50", "--no-cpu", "--no-extra"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+    plain, rec = [], []
+    for _ in range(3):
+        plain.append(run([]))
+        rec.append(run(["--record-graphs"]))
+    assert abs(max(rec) / max(plain) - 1.0) < 0.03, (plain, rec)

@@ -184,3 +184,34 @@ def test_track_chunk_equals_frame_by_frame_tracking():
     assert len(bt._chunk_graphs) == 2
     with pytest.raises(ValueError):
         bt.track_chunk(vids[1:3, :2])
+
+
+# Tracker-realistic crop sides -> the two network input sizes, incl. exact 2x / 4x downsamples, identity and upsamples
+CV2_CASES = [(90, 128), (131, 128), (256, 128), (512, 128), (700, 128), (64, 128), (128, 128),
+             (97, 256), (300, 256), (512, 256), (1024, 256), (333, 256), (701, 256), (128, 256)]
+
+
+def test_resize_equals_cv2_when_the_box_has_opencv():
+    """SURVEY 8(f)1 pin: `cv.resize` (default INTER_LINEAR on uint8, lib/train/data/processing_utils.py:68) against BOTH the numpy
+    port (host_ops.resize_bilinear_u8) and the device kernel (vt_crop), bit for bit.  Runs only where OpenCV is importable; the
+    build image and -- as far as known -- the GPU box do not have it, in which case the skip reason says so and the resize
+    stays parity-unpinned."""
+    try:
+        import cv2
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"cv2 is not importable on this box ({type(e).__name__}: {e}): the bilinear resize stays unpinned against OpenCV")
+    import torch
+    from vittracker_amd.host_ops import resize_bilinear_u8
+    rs = np.random.RandomState(9)
+    m = _nat(B=1)
+    for S, T in CV2_CASES:
+        im = rs.randint(0, 256, (S + 24, S + 24, 3)).astype(np.uint8)
+        x1 = y1 = 12                                               # the crop lies strictly inside the frame: no padding involved
+        want = cv2.resize(im[y1:y1 + S, x1:x1 + S], (T, T))
+        np.testing.assert_array_equal(resize_bilinear_u8(np.ascontiguousarray(im[y1:y1 + S, x1:x1 + S]), T, T), want, err_msg=f"port {S}->{T}")
+        # a box whose crop is exactly that square: side = ceil(sqrt(w h) * factor) = S with w = h = S / 2, factor 2
+        box = torch.tensor([[x1 + S / 4.0, y1 + S / 4.0, S / 2.0, S / 2.0]], dtype=torch.float64).cuda()
+        crop, rf = m.crop(torch.from_numpy(im[None]).cuda(), box, 2.0, T, [0, 0, 0], [1, 1, 1])
+        assert float(rf[0]) == T / S
+        got = np.rint(crop[0].cpu().numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+        np.testing.assert_array_equal(got, want, err_msg=f"vt_crop {S}->{T}")

@@ -58,3 +58,40 @@ def test_variant_matches_reference_golden(name):
     env = dict(os.environ, **VARIANTS[name])
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+
+
+# A step captured as N parallel chains over frame slices (VT_GRAPH_CHAINS, vt_graph_capture_steps): the chains run concurrently,
+# so every per-frame workspace -- the tile-form blocks' q / K / V^T / residual sets included -- must be sliced by the chain's
+# first frame.  Graph replay == the eager step, bit for bit, at batches that select the tile form (small) and the frame form.
+CHAINS_CODE = r"""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import GEOMS
+from vittracker_amd import native, synth
+assert torch.cuda.is_available()
+for geom, batches in (("G128", (2, 7, 96)), ("G256", (2, 7, 40))):
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(5, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    for B in batches:
+        m = native.Model(tz, tx, max_batch=B); m.load_state_dict(sd)
+        z, x = synth.synth_inputs(40 + B, B, tz, tx)
+        zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+        ref = m.forward(zd, xd)
+        ref = {k: getattr(ref, k).clone() for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")}
+        graph, out = m.capture(zd, xd)
+        for _ in range(3):
+            graph.launch()
+        torch.cuda.synchronize()
+        for k, v in ref.items():
+            assert torch.equal(getattr(out, k), v), (geom, B, k)
+        graph = None; m.close()
+print("OK")
+""" % {"root": ROOT}
+
+
+@pytest.mark.parametrize("chains", ["2", "3"])
+def test_graph_chains_match_eager(chains):
+    env = dict(os.environ, VT_GRAPH_CHAINS=chains)
+    r = subprocess.run([sys.executable, "-c", CHAINS_CODE], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])

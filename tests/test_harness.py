@@ -179,6 +179,37 @@ def test_batched_runner_frames_per_launch_writes_the_same_files(monkeypatch, tmp
     assert texts[0] == texts[1]
 
 
+def test_batched_runner_isolates_bad_sequences_and_failing_groups(monkeypatch, tmp_path, capsys):
+    """The reference prints the error and skips only that sequence (lib/test/evaluation/running.py:138-142).  Lock-step form: a
+    too-small init box is screened out per sequence before grouping; a group that raises mid-run is reported and skipped while
+    the groups before and after it are written; one pipeline per batch size is built and reused."""
+    from vittracker_amd.evaluation import Tracker, get_dataset
+    from vittracker_amd.evaluation.running import run_dataset_batched
+    monkeypatch.setenv("VITTRACK_SAVE_DIR", str(tmp_path))
+    ds = get_dataset("synthetic:10x5")
+    ds[1].ground_truth_rect[0, 2:] = 0.0                  # zero-size init box -> "Too small bounding box."
+    t = Tracker("vit_dist", "vit_48_h32_noKD", "synthetic")
+
+    class Flaky(_FakeBatched):
+        calls = 0
+
+        def initialize(self, frames, boxes):
+            Flaky.calls += 1
+            if Flaky.calls == 2:
+                raise RuntimeError("boom in group 2")
+            super().initialize(frames, boxes)
+    _FakeBatched.instances.clear()
+    out = run_dataset_batched(ds, t, batch=3, params=_Params(), make_batched=Flaky)      # 9 good sequences -> groups of 3, 3, 3
+    txt = capsys.readouterr().out
+    assert "Too small bounding box." in txt and ds[1].name in txt and "boom in group 2" in txt
+    good = [s for i, s in enumerate(ds) if i != 1]
+    done = [s.name for s in good[:3] + good[6:]]
+    assert sorted(out) == sorted(done)
+    for s in ds:
+        assert os.path.exists(os.path.join(t.results_dir, s.name + ".txt")) == (s.name in done)
+    assert [b.B for b in _FakeBatched.instances] == [3, 3]      # built once, reused for group 2 (which failed), rebuilt for group 3
+
+
 def test_deploy_wire_signature():
     from vittracker_amd import deploy
     ins, outs = deploy.wire_signature()

@@ -218,18 +218,21 @@ def test_result_gather_two_ranks_gloo(tmp_path):
 
 
 # ---------------------------------------------------------------- bench.py launcher (no GPU: gloo, compute skipped)
-def test_bench_self_launches_two_ranks_plumbing_only():
-    """`python bench.py --gpus 2` with no torch.distributed.run wrapper: the parent spawns the ranks as a
-    child, relays ONE JSON line and exits with the child's code (here on gloo with compute skipped)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launches_ranks_plumbing_only(world):
+    """`python bench.py --gpus N` with no torch.distributed.run wrapper: the parent spawns the ranks as a
+    child, relays ONE JSON line and exits with the child's code (here on gloo with compute skipped).  N = 8 is the driver's
+    SCALE configuration (BASELINE config 3)."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "7",
-                        "--steps-per-graph", "3", "--warmup", "1", "--batch", "8"], env=env, capture_output=True, text=True, timeout=300)
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--plumbing-only", "--steps", "7",
+                        "--steps-per-graph", "3", "--warmup", "1", "--batch", "8"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and len(j["per_rank_frames_per_s"]) == 2
+    assert j["n_gpus"] == world and j["config"]["global_batch"] == 8 * world and len(j["per_rank_frames_per_s"]) == world
     assert "gather_exposed_us_per_step" in j and j["scaling"] == "weak"
     assert j["steps"] == 7 and j["config"]["steps_per_graph"] == 3      # 2 launch units of 3 steps + 1 single step
 

@@ -20,6 +20,11 @@ def macs():
 
 
 def run(a):
+    print(json.dumps(measure(a)), flush=True)
+
+
+def measure(a):
+    """One timed ViT-Base run; returns the JSON line as a dict (bench.py's default run quotes it under `also`)."""
     import torch
     from vittracker_amd import native, synth
     if a.gpus != 1:
@@ -93,4 +98,6 @@ def run(a):
                             "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "flop_per_launch": flop_blocks,
                             "avg_launch_us": round(t_blocks, 1)}
-    print(json.dumps(line), flush=True)
+    graph = None
+    m.close()
+    return line

@@ -101,6 +101,7 @@ struct vt_model {
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
     int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
+    bool r4_128_forced = false;   // VT_STEM_R4_128 was set: keep that band height at every batch size
 };
 
 struct vt_graph {
@@ -261,7 +262,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     const StemPlan pz{m->plan_r2[1], m->plan_r4[1]};
     // small batches of the 128-px search crop: stem_b in bands of 2 token rows (4 workgroups per crop instead of 2) shortens the
     // latency chain of a band (B=1 step 63.5 -> 59.9 us); at large batches the halo rows it recomputes cost more than that
-    if (Tx == 128 && B <= 80 && px.r4 == 4 && !std::getenv("VT_STEM_R4_128")) px.r4 = 2;
+    if (Tx == 128 && B <= 80 && px.r4 == 4 && !m->r4_128_forced) px.r4 = 2;
     for (const auto& pr : {std::make_pair(Tx, px), std::make_pair(Tz, pz)}) {
         const int T = pr.first, r2 = pr.second.r2, r4 = pr.second.r4;
         const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
@@ -360,21 +361,25 @@ int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int n
 
 // Small batches: one wave per (tile, frame), two launches per block (vt_blocks_tile.h).
 template <int NT>
-int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zc) {
-    // two workspace sets: a block reads q / K / V^T from one while its workgroups write the next block's into the other
+int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zc, size_t f0) {
+    // two workspace sets: a block reads q / K / V^T from one while its workgroups write the next block's into the other.
+    // f0 = first frame of this slice in the model workspace: the chains of a multi-chain graph (vt_graph_capture_steps) run
+    // concurrently on different slices, so each works in its own part of every workspace.
     const size_t set = (size_t)m->tile_frames * m->L * 48 / 4;                  // float4 per set
-    f4* const qb = reinterpret_cast<f4*>(m->tile_q.p);
-    f4* const kb = reinterpret_cast<f4*>(m->tile_k.p);
-    f4* const vb = reinterpret_cast<f4*>(m->tile_v.p);
+    const size_t sl = f0 * m->L * 48 / 4;                                       // float4 offset of the slice inside a set
+    f4* const qb = reinterpret_cast<f4*>(m->tile_q.p) + sl;
+    f4* const kb = reinterpret_cast<f4*>(m->tile_k.p) + sl;
+    f4* const vb = reinterpret_cast<f4*>(m->tile_v.p) + sl;
+    float* const tile_x = m->tile_x.p + f0 * m->L * 48;
     const float* const normP = m->blocks.p + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;      // norm.weight, norm.bias
     hipLaunchKernelGGL((vtb::tile_qkv_kernel<NT>), dim3(NT, B), dim3(64), 0, st, tokens, m->blocks.p, qb, kb, vb, m->zcache.p, zc, m->len_z);
     for (int blk = 0; blk < nblocks; ++blk) {
         const float* P = m->blocks.p + (size_t)blk * vtb::BLOCK_STRIDE;
-        const float* xin = blk == 0 ? tokens : m->tile_x.p;
+        const float* xin = blk == 0 ? tokens : tile_x;
         const bool last = blk == nblocks - 1;
         const int skip_z = (blk == m->cfg.depth - 1 && resid == nullptr) ? 1 : 0;
         const size_t cur = (size_t)(blk & 1) * set, nxt = (size_t)((blk & 1) ^ 1) * set;
-        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(256), 0, st, xin, m->tile_x.p, P, qb + cur, kb + cur, vb + cur,
+        hipLaunchKernelGGL((vtb::tile_attn_mlp_kernel<NT>), dim3(NT, B), dim3(256), 0, st, xin, tile_x, P, qb + cur, kb + cur, vb + cur,
                            last ? normP : nullptr, feat, last ? resid : nullptr, m->len_z, skip_z,
                            last ? nullptr : P + vtb::BLOCK_STRIDE, qb + nxt, kb + nxt, vb + nxt);
     }
@@ -382,8 +387,9 @@ int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, 
     return VT_OK;
 }
 
-int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid, int zc = 0) {
-    // zc: template cache mode of block 0 (0 off, 1 store, 2 load)
+int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid, int zc = 0, size_t f0 = 0) {
+    // zc: template cache mode of block 0 (0 off, 1 store, 2 load); f0: first frame of this slice in the model workspace
+    if (zc != 0 && f0 != 0) return fail(VT_ERR_STATE, "the template cache is not sliced");
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     // Kernel form by batch size: with few frames a workgroup per frame leaves most of the chip idle (a frame's latency is one
     // CU's worth of MFMA issue); one wave per tile spreads frames x tiles over the SIMDs instead.
@@ -392,9 +398,9 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 86, B=32 300 -> 136,
     // B=64 314 -> 183, B=128 371 -> 315; G128 B=1 78 -> 59, B=16 79 -> 62, B=64 84 -> 83, B=80 88 -> 86, B=96 95 -> 95
     const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 80) : m->blocks_tile != 0;
-    if (want_tile && !diag && nblocks >= 1 && B <= m->tile_frames && (NTr == 5 || NTr == 20))
-        return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc)
-                        : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc);
+    if (want_tile && !diag && nblocks >= 1 && f0 + (size_t)B <= (size_t)m->tile_frames && (NTr == 5 || NTr == 20))
+        return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc, f0)
+                        : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc, f0);
     switch (m->L / 16) {
         case 5:
             if (m->blocks_bal) return zc ? launch_blocks<5, 8, 1, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
@@ -655,6 +661,8 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
+        const char* v = std::getenv("VT_STEM_R4_128");
+        m->r4_128_forced = v && *v;
     }
     if (!rc && env_int("VT_DBG_STAMPS", 0)) {
         if (hipMalloc(reinterpret_cast<void**>(&m->dbg_stamps), B * 8 * 64 * sizeof(unsigned long long)) != hipSuccess)
@@ -973,7 +981,7 @@ static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0,
     float* feat = m->feat.p + f0 * m->len_x * 48;
     int rc;
     if ((rc = run_stem(m, z + f0 * 3 * Tz * Tz, x + f0 * 3 * Tx * Tx, nb, st, tok, f0))) return rc;
-    if ((rc = run_blocks(m, tok, nb, -1, st, feat, nullptr))) return rc;
+    if ((rc = run_blocks(m, tok, nb, -1, st, feat, nullptr, 0, f0))) return rc;
     return run_head(m, feat, nb, st, out, f0);
 }
 

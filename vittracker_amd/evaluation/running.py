@@ -89,38 +89,66 @@ def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=Non
     if make_batched is None:
         from ..batched import BatchedVitTracker
         make_batched = BatchedVitTracker
+    # A sequence whose init box is too small to crop makes `sample_target` raise in the reference (processing_utils.py:33-34),
+    # and `run_sequence` prints the error and skips THAT sequence (running.py:138-142): screened out here, per sequence, before
+    # the lock-step groups are formed, so one bad box does not cost its whole group.
+    import math
+    ok = []
+    for s in todo:
+        try:
+            x, y, w, h = [float(v) for v in s.init_info()["init_bbox"]]
+            for f in (params.template_factor, params.search_factor):
+                if not math.ceil(math.sqrt(w * h) * f) >= 1:
+                    raise Exception("Too small bounding box.")
+            ok.append(s)
+        except Exception as e:  # noqa: BLE001
+            print("Tracker: {} {} {} ,  Sequence: {}".format(tracker.name, tracker.parameter_name, tracker.run_id, s.name))
+            print(e)
     outputs = {}
-    for (H, W), seqs in _groups(todo, batch):
-        B = len(seqs)
-        bt = make_batched(params, B)
-        T = max(len(s) for s in seqs)
-        frame = lambda s, t: read_image(s.frames[min(t, len(s) - 1)])  # noqa: E731
-        out = {s.name: {"target_bbox": [list(s.init_info()["init_bbox"])], "time": []} for s in seqs}
-        t0 = time.time()
-        bt.initialize(np.stack([frame(s, 0) for s in seqs]), [s.init_info()["init_bbox"] for s in seqs])
-        dt = (time.time() - t0) / B
-        for s in seqs:
-            out[s.name]["time"].append(dt)
-        n = max(1, int(frames_per_launch))
-        t = 1
-        while t < T:
-            k = n if (n > 1 and t + n <= T and hasattr(bt, "track_chunk")) else 1      # whole chunks, then frame by frame
-            t0 = time.time()
-            if k == 1:
-                boxes = bt.track(np.stack([frame(s, t) for s in seqs]))["target_bbox"].numpy()[None]     # sync=True: boxes on the host
-            else:
-                boxes = bt.track_chunk(np.stack([np.stack([frame(s, t + j) for s in seqs]) for j in range(k)]))["target_bbox"].numpy()
-            wall = (time.time() - t0) / k
-            for j in range(k):
-                live = sum(1 for s in seqs if t + j < len(s))
-                for b, s in enumerate(seqs):
-                    if t + j < len(s):
-                        out[s.name]["target_bbox"].append(boxes[j, b].tolist())
-                        out[s.name]["time"].append(wall / live)
-            t += k
-        for s in seqs:
-            save_tracker_output(s, tracker.results_dir, out[s.name])
-            print("Tracker: {} {} {} ,  Sequence: {}  FPS: {}".format(tracker.name, tracker.parameter_name, tracker.run_id, s.name,
-                                                                     len(out[s.name]["time"]) / sum(out[s.name]["time"])))
-        outputs.update(out)
+    pipelines = {}       # batch size -> BatchedVitTracker: weights, workspaces and captured graphs are built once per size
+    for (H, W), seqs in _groups(ok, batch):
+        try:
+            outputs.update(_run_group(seqs, tracker, params, make_batched, pipelines, frames_per_launch))
+        except Exception as e:  # noqa: BLE001  (a failing group is reported and skipped; finished groups are already on disk)
+            print("Tracker: {} {} {} ,  Sequences: {}".format(tracker.name, tracker.parameter_name, tracker.run_id, [s.name for s in seqs]))
+            print(e)
+            pipelines.clear()        # a pipeline that raised mid-run is not reused
     return outputs
+
+
+def _run_group(seqs, tracker, params, make_batched, pipelines, frames_per_launch):
+    """One lock-step group (same frame size, <= batch sequences); results are written when the group is done."""
+    B = len(seqs)
+    bt = pipelines.get(B)
+    if bt is None:
+        bt = pipelines[B] = make_batched(params, B)
+    T = max(len(s) for s in seqs)
+    frame = lambda s, t: read_image(s.frames[min(t, len(s) - 1)])  # noqa: E731
+    out = {s.name: {"target_bbox": [list(s.init_info()["init_bbox"])], "time": []} for s in seqs}
+    t0 = time.time()
+    bt.initialize(np.stack([frame(s, 0) for s in seqs]), [s.init_info()["init_bbox"] for s in seqs])
+    dt = (time.time() - t0) / B
+    for s in seqs:
+        out[s.name]["time"].append(dt)
+    n = max(1, int(frames_per_launch))
+    t = 1
+    while t < T:
+        k = n if (n > 1 and t + n <= T and hasattr(bt, "track_chunk")) else 1      # whole chunks, then frame by frame
+        t0 = time.time()
+        if k == 1:
+            boxes = bt.track(np.stack([frame(s, t) for s in seqs]))["target_bbox"].numpy()[None]     # sync=True: boxes on the host
+        else:
+            boxes = bt.track_chunk(np.stack([np.stack([frame(s, t + j) for s in seqs]) for j in range(k)]))["target_bbox"].numpy()
+        wall = (time.time() - t0) / k
+        for j in range(k):
+            live = sum(1 for s in seqs if t + j < len(s))
+            for b, s in enumerate(seqs):
+                if t + j < len(s):
+                    out[s.name]["target_bbox"].append(boxes[j, b].tolist())
+                    out[s.name]["time"].append(wall / live)
+        t += k
+    for s in seqs:
+        save_tracker_output(s, tracker.results_dir, out[s.name])
+        print("Tracker: {} {} {} ,  Sequence: {}  FPS: {}".format(tracker.name, tracker.parameter_name, tracker.run_id, s.name,
+                                                                 len(out[s.name]["time"]) / sum(out[s.name]["time"])))
+    return out

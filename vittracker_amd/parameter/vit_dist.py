@@ -8,9 +8,11 @@ from ..evaluation.environment import env_settings
 from ..params import TrackerParams
 
 
-def parameters(yaml_name: str):
+def parameters(yaml_name: str, env=None):
+    """`env`: an object with `prj_dir` / `save_dir` (the reference's `env_settings()`, i.e. the user's local.py, when this runs
+    inside the reference tree -- integration/lib/test/parameter/vit_dist.py passes it); default: this repo's own settings."""
     params = TrackerParams()
-    env = env_settings()
+    env = env_settings() if env is None else env
     update_config_from_file(os.path.join(env.prj_dir, "experiments/vit_dist/%s.yaml" % yaml_name))
     params.cfg = cfg
     params.template_factor = cfg.TEST.TEMPLATE_FACTOR

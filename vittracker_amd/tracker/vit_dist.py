@@ -128,7 +128,10 @@ class Vit_dist(BaseTracker):
             out = self._bt.track(image[None])                # sync=True: state and confidence on the host
             self.state = out["target_bbox"][0].tolist()
             if self.save_all_boxes:
-                return {"target_bbox": self.state, "all_boxes": list(self.state)}
+                # rare mode: two more small copies for the un-clipped box (the windowed decode and this frame's resize factor)
+                pred_boxes = self._bt.out.hann_boxes.cpu().view(-1, 4)
+                resize_factor = float(self._bt.rf.cpu()[0])
+                return {"target_bbox": self.state, "all_boxes": self._all_boxes(pred_boxes, resize_factor)}
             return {"target_bbox": self.state, "confidence": float(out["confidence"][0])}
         x_patch_arr, resize_factor, x_amask_arr = sample_target(image, self.state, self.params.search_factor,
                                                                 output_sz=self.params.search_size)
@@ -148,7 +151,7 @@ class Vit_dist(BaseTracker):
         self.state = clip_box(self.map_box_back(pred_box, resize_factor), H, W, margin=10)
 
         if self.save_all_boxes:
-            return {"target_bbox": self.state, "all_boxes": list(self.state)}
+            return {"target_bbox": self.state, "all_boxes": self._all_boxes(rec[:4].clone().view(1, 4), resize_factor)}
         return {"target_bbox": self.state, "confidence": float(rec[4])}
 
     def map_box_back(self, pred_box: list, resize_factor: float):
@@ -159,6 +162,24 @@ class Vit_dist(BaseTracker):
         cx_real = cx + (cx_prev - half_side)
         cy_real = cy + (cy_prev - half_side)
         return [cx_real - 0.5 * w, cy_real - 0.5 * h, w, h]
+
+
+    def map_box_back_batch(self, pred_box, resize_factor: float):
+        """:158-164 -- float32 tensor arithmetic, offsets from Python floats, like the reference"""
+        import torch
+        cx_prev, cy_prev = self.state[0] + 0.5 * self.state[2], self.state[1] + 0.5 * self.state[3]
+        cx, cy, w, h = pred_box.unbind(-1)
+        half_side = 0.5 * self.params.search_size / resize_factor
+        cx_real = cx + (cx_prev - half_side)
+        cy_real = cy + (cy_prev - half_side)
+        return torch.stack([cx_real - 0.5 * w, cy_real - 0.5 * h, w, h], dim=-1)
+
+    def _all_boxes(self, pred_boxes, resize_factor: float):
+        """`save_all_boxes` record of one frame (:141-146): every predicted box (one here) scaled to crop pixels and mapped
+        back WITHOUT clipping -- and, as in the reference, relative to `self.state` as it is at that point, i.e. the state
+        this frame has just produced, not the one the crop was taken around."""
+        all_boxes = self.map_box_back_batch(pred_boxes * self.params.search_size / resize_factor, resize_factor)
+        return all_boxes.view(-1).tolist()
 
 
 def get_tracker_class():
