@@ -21,7 +21,7 @@ def test_yaml_merge_and_strict_keys(tmp_path):
     g = config.geometry(c)
     assert (g["channels"], g["heads"], g["head_channels"]) == (48, 1, 32)          # "h32" = head width, 1 attention head
     assert (g["template_size"], g["search_size"], g["feat_sz"], g["len_z"], g["len_x"]) == (128, 256, 16, 64, 256)
-    assert c.TRAIN.LR == 0.0001                                                    # untouched default survives
+    assert c.TRAIN.LR == 0.0004 and c.TRAIN.AUX_WEIGHT == 1.0                      # set by the YAML / untouched default survives
     bad = tmp_path / "bad.yaml"
     bad.write_text("MODEL:\n  BACKBONE:\n    NOT_A_KEY: 1\n")
     with pytest.raises(ValueError, match="NOT_A_KEY not exist in config.py"):
