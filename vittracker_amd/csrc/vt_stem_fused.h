@@ -59,6 +59,7 @@ struct FusedGeo {                       // TX = 128, TZ = 64
 template <bool IS_Z, int XB>
 struct BandF {
     using G = FusedGeo;
+    static constexpr bool is_z = IS_Z;
     static constexpr int T = IS_Z ? G::TZ : G::TX;
     static constexpr int lgT = IS_Z ? 6 : 7, HALF = T >> 2, lgHALF = lgT - 2, PITCH = (T >> 1) + 1;
     static constexpr int npix1 = IS_Z ? G::NPIX1Z : G::NPIX1X;
@@ -113,25 +114,38 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const BandF<false, 3> bx3{xin_b};
 
     // ---- layer 1 pieces ------------------------------------------------------------------------------
-    const int pair = gw * 64 + lane;                         // this thread's pixel pair of a band (0..511)
+    const int pair_ = gw * 64 + lane;                        // this thread's pixel pair of a band (0..511)
+    // Every phase derives its indices and LDS addresses from a FRESH copy of the thread's index: left to itself hipcc shares
+    // those sub-expressions between the five bands' phases, keeps them all live from the first use on and runs out of registers
+    // (36 B/lane of scratch, with the spill's wait in front of the first band's loads).
+    auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
     // Raw loads only: nothing here may depend on the loaded data, so the requests stay in flight across
     // the layer-2 work and the barrier that follow (the top-of-image zeroing is applied in layer1).
+    // Buffer loads (scalar descriptor + one 32-bit offset VGPR; kernel rows 1 and 2 are immediate offsets of the same register,
+    // the channel plane is the scalar offset): a fetch holds 2 address registers instead of 9 64-bit pairs.
+    const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin_b), 0, 3 * G::TZ * G::TZ * 4, 0x00020000);
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin_b), 0, 3 * G::TX * G::TX * 4, 0x00020000);
     auto fetch = [&](const auto& J, f4 (&v)[3][3]) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const int pair = fresh(pair_);
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const int p1 = 2 * J.p0 - 1 + lr;                    // layer-1 row (>= 0)
+        const unsigned off1 = ((((unsigned)(2 * p1)) << J.lgT) + 4u * (unsigned)qp) << 2;      // input row 2 p1 (kernel row 1), bytes
+        const unsigned off0 = p1 > 0 ? off1 - (4u << J.lgT) : off1;                            // row 2 p1 - 1; the image top reads row 0 (zeroed in layer1)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            int iy = 2 * p1 + r - 1;                         // -1 only at the image top
-            iy = iy >= 0 ? iy : 0;
-            const unsigned off = ((unsigned)iy << J.lgT) + 4u * (unsigned)qp;
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off);
-        }
+            for (int c = 0; c < 3; ++c) {
+                const u4 t = __builtin_amdgcn_raw_buffer_load_b128(J.is_z ? rsrc_z : rsrc_x, r == 0 ? off0 : off1 + (r == 2 ? (4u << J.lgT) : 0u),
+                                                                   c << (2 * J.lgT + 2), 0);
+                v[r][c] = __builtin_bit_cast(f4, t);
+            }
     };
     auto layer1 = [&](const auto& J, const f4 (&v)[3][3]) {
         // layer 1 is the long pole of an interval (VALU-bound); without this the issue arbiter favours the
         // older group whatever it is doing, and the younger group's layer 1 takes three times as long
         __builtin_amdgcn_s_setprio(3);
+        const int pair = fresh(pair_);
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const float keep0 = (2 * J.p0 - 1 + lr) > 0 ? 1.f : 0.f;   // kernel row 0 of layer-1 row 0 is the zero padding
         // housekeeping by a few threads: column -1 of every ring row, and the halo row
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         // Four waves of the group (one per SIMD) cover the band's 16 tiles; the other four go straight to the barrier.
         if (gw < 4) {
             typedef float f16v __attribute__((ext_vector_type(16)));
+            const int ln = fresh(lane), q = ln >> 4, px = ln & 15;
             const int op = 16 * (4 * gw + q) + px, yy = op >> J.lgW2, xx = op & ((1 << J.lgW2) - 1);
             const f4* src = ring + 2 * yy * J.PITCH + xx;                     // tap (0,0) of this lane's pixel, channel quad 0
             const f4* wk = cw2 + px;                                          // [tap][channels 0-3 | 4-5][16 output channels] float4: 16 lanes read 16 consecutive entries
@@ -261,21 +276,36 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         }
     };
     stamp();
-    // ---- start: the first bands' inputs are requested before the LDS is cleared ---------------------------
+    // ---- start ---------------------------------------------------------------------------------------------------------
+    // Order in the memory queue: (1) this thread's constant (tiny, cache-resident), (2) group A's first band -- the template
+    // crop, which the first interval computes on, (3) group B's first band, needed one interval later.  The constant's load is
+    // older than the crop fetch, so the LDS write below waits for it alone (counted vmcnt); issued after the fetch it sat behind
+    // 26 MB of crop requests from all workgroups (a 5-8 k cycle prologue).
     f4 v[3][3];
-    if (grp == 0) { if (do_z) fetch(bz, v); } else if (do_x) fetch(bx0, v);
-    {   // constants -> LDS; zero only what is read without ever being written: the top rows of the rings,
-        // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
-        const int t = threadIdx.x;
+    const int t = threadIdx.x;
 #ifndef VT_F16
-        if (t < 9 * 32) cw2[t] = ld4(w2k + 4 * t);           // [tap][2][16][4] floats: layer-2 weights for the 4-block MFMA
+    constexpr int NW2 = 9 * 32;                              // [tap][2][16][4] floats: layer-2 weights for the 4-block MFMA
+    const float* const w2src = w2k;
 #else
-        if (t < 5 * 64) cw2[t] = ld4(w2img + 4 * t);
+    constexpr int NW2 = 5 * 64;
+    const float* const w2src = w2img;
 #endif
-        else if (t < 5 * 64) {}
-        else if (t < 5 * 64 + 4) cw2[t] = ld4(b2 + 4 * (t - 320));
-        else if (t < 5 * 64 + 12) cw2[t] = ld4(b3 + 4 * (t - 324));
-        else if (t < 5 * 64 + 24) cw2[t] = ld4(b4 + 4 * (t - 332));
+    const float* csrc = w2src;                               // threads without a constant load a valid address and drop it
+    const bool has_c = t < NW2 || (t >= 320 && t < 344);
+    if (t < NW2) csrc = w2src + 4 * t;
+    else if (t >= 320 && t < 324) csrc = b2 + 4 * (t - 320);
+    else if (t >= 324 && t < 332) csrc = b3 + 4 * (t - 324);
+    else if (t >= 332 && t < 344) csrc = b4 + 4 * (t - 332);
+    const f4 cst = ld4(csrc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) {      // every thread that holds a constant is in group A (t < 344): fetch and LDS write in one straight line,
+                         // so the wait in front of the write is a counted one (the nine crop loads stay in flight)
+        if (do_z) fetch(bz, v);
+        if (has_c) cw2[t] = cst;
+    }
+    {   // zero only what is read without ever being written: the top rows of the rings,
+        // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
+        if (t < 384) {}
         else if (t >= 384 && t < 384 + 2 * 65) {                        // ring B, row 0 (first used by x0: image top)
             const int e = t - 384, pl = e / 65, col = e - pl * 65;
             ring0[G::RING + pl * G::NPIX1X + col] = splat4(0.f);
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             m2[M2Z_OFF + pl * G::NPIX2Z + (k < 17 ? k : (k - 17) * 17 + 8)] = splat4(0.f);
         }
     }
+    if (grp == 1 && do_x) fetch(bx0, v);     // behind group A's requests (delaying it further changed nothing: measured)
     stamp();
     // No barrier here: nothing written above is read before the first interval's barrier (layer 1 reads no LDS,
     // and its ring writes do not overlap the entries cleared above).
@@ -308,25 +339,30 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     if (!(skip & 1)) {
         const bool l2 = !(skip & 2);
         // zmode: a crop that is not wanted keeps its barriers and drops its work (all conditions are wave-uniform)
+        // The next band's input is requested one interval ahead: by the four waves without layer-2 work (gw >= 4) at the start of
+        // the interval, by the four that run layer 2 right after it (its accumulators, double-buffered operands and the nine
+        // prefetched float4 together do not fit in 128 registers; layer 2 takes a third of the interval, the rest covers the loads).
+        auto l2_and_fetch = [&](const auto& J2, bool run2, const auto& Jn, bool run_f) {
+            if (run_f && gw >= 4) fetch(Jn, v);
+            if (run2) layer2(J2);
+            if (run_f && gw < 4) fetch(Jn, v);
+        };
         if (grp == 0) {
-            if (do_z) layer1(bz, v);                stamp(); __syncthreads(); stamp();   // 0: L1(z)
-            if (do_x) fetch(bx1, v);
-            if (l2 && do_z) layer2(bz);             stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
-            if (do_x) layer1(bx1, v);               stamp(); __syncthreads(); stamp();   // 2: L1(x1)
-            if (do_x) fetch(bx3, v);
-            if (l2 && do_x) layer2(bx1);            stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
-            if (do_x) layer1(bx3, v);               stamp(); __syncthreads(); stamp();   // 4: L1(x3)
-            load_w3();
-            if (l2 && do_x) layer2(bx3);            stamp(); __syncthreads(); stamp();   // 5: L2(x3)
+            if (do_z) layer1(bz, v);                    stamp(); __syncthreads(); stamp();   // 0: L1(z)
+            l2_and_fetch(bz, l2 && do_z, bx1, do_x);    stamp(); __syncthreads(); stamp();   // 1: L2(z), x1 requested
+            if (do_x) layer1(bx1, v);                   stamp(); __syncthreads(); stamp();   // 2: L1(x1)
+            l2_and_fetch(bx1, l2 && do_x, bx3, do_x);   stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
+            if (do_x) layer1(bx3, v);                   stamp(); __syncthreads(); stamp();   // 4: L1(x3)
+            if (l2 && do_x) layer2(bx3);                stamp(); __syncthreads(); stamp();   // 5: L2(x3)
         } else {
             stamp(); __syncthreads(); stamp();   // 0: (x0 requested at kernel start)
-            if (do_x) layer1(bx0, v);               stamp(); __syncthreads(); stamp();   // 1: L1(x0)
-            if (do_x) fetch(bx2, v);
-            if (l2 && do_x) layer2(bx0);            stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
-            if (do_x) layer1(bx2, v);               stamp(); __syncthreads(); stamp();   // 3: L1(x2)
-            if (l2 && do_x) layer2(bx2);            stamp(); __syncthreads(); stamp();   // 4: L2(x2)
-            load_w3();                              __syncthreads();   // 5
+            if (do_x) layer1(bx0, v);                   stamp(); __syncthreads(); stamp();   // 1: L1(x0)
+            l2_and_fetch(bx0, l2 && do_x, bx2, do_x);   stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
+            if (do_x) layer1(bx2, v);                   stamp(); __syncthreads(); stamp();   // 3: L1(x2)
+            if (l2 && do_x) layer2(bx2);                stamp(); __syncthreads(); stamp();   // 4: L2(x2)
+            __syncthreads();   // 5
         }
+        load_w3();
     }
 
     // ---- layer 3 (12 -> 24, Hardswish) on the whole maps, all 16 waves -------------------------------------
@@ -451,7 +487,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     struct Band {
         const float* in; float* out;
         int lgT, HALF, lgHALF, PITCH, npix1, p0, R2, lgW2;
-        bool halo;
+        bool halo, is_z;
     };
     auto band = [&](int j) {       // j-th band of the frame: template bands first
         Band J;
@@ -463,20 +499,27 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
         J.out = is_z ? act_z + (size_t)b * 3 * (TZ / 4) * (TZ / 4) * 4 : act_x + (size_t)b * 3 * (TX / 4) * (TX / 4) * 4;
         J.lgT = is_z ? lgTZ : lgTX; J.HALF = (is_z ? TZ : TX) >> 2; J.lgHALF = J.lgT - 2; J.PITCH = ((is_z ? TZ : TX) >> 1) + 1;
         J.npix1 = is_z ? G::NPIX1Z : G::NPIX1X; J.R2 = is_z ? G::R2Z : G::R2X; J.p0 = kb * J.R2; J.lgW2 = J.lgT - 2;
-        J.halo = kb > 0;
+        J.halo = kb > 0; J.is_z = is_z;
         return J;
     };
+    // buffer loads: scalar descriptor + one 32-bit offset register per kernel row pair (see stem_fused_kernel)
+    const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin + (size_t)b * 3 * TZ * TZ), 0, 3 * TZ * TZ * 4, 0x00020000);
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX * 4, 0x00020000);
     auto fetch = [&](const Band& J, f4 (&v)[3][3]) {           // raw loads only (see stem_fused_kernel)
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const int p1 = 2 * J.p0 - 1 + lr;
+        const unsigned off1 = ((((unsigned)(2 * p1)) << J.lgT) + 4u * (unsigned)qp) << 2;
+        const unsigned off0 = p1 > 0 ? off1 - (4u << J.lgT) : off1;
+        const unsigned off2 = off1 + (4u << J.lgT);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            int iy = 2 * p1 + r - 1;
-            iy = iy >= 0 ? iy : 0;
-            const unsigned off = ((unsigned)iy << J.lgT) + 4u * (unsigned)qp;
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) v[r][c] = ld4(J.in + ((size_t)c << (2 * J.lgT)) + off);
-        }
+            for (int c = 0; c < 3; ++c) {
+                const unsigned vo = r == 0 ? off0 : (r == 1 ? off1 : off2), so = (unsigned)c << (2 * J.lgT + 2);
+                const u4 t = J.is_z ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo, so, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, so, 0);
+                v[r][c] = __builtin_bit_cast(f4, t);
+            }
     };
     auto layer1 = [&](const Band& J, const f4 (&v)[3][3]) {
         __builtin_amdgcn_s_setprio(3);
