@@ -53,7 +53,7 @@ enum Epi {
     EPI_PATCH = 0,   // resid[m][n] = acc + bias[n] + pos[m % L][n]                     (f32 out)
     EPI_BF16 = 1,    // out[m][n] = bf16(acc + bias[n])                                  (q (pre-scaled) and k projections)
     EPI_RESID = 2,   // resid[m][n] += acc + bias[n]                                     (f32 read-modify-write)
-    EPI_GELU = 3,    // out[m][n] = bf16(gelu_erf(acc + bias[n]))
+    EPI_GELU = 3,    // out[m][n] = bf16(gelu(acc + bias[n]))
     EPI_CONV = 4,    // out[map row of m][n] = bf16(relu(acc + bias[n]))                 (head towers, BN folded)
     EPI_VT = 5,      // vt[frame][n][token] = bf16(acc + bias[n]): the v projection, stored transposed (operands swapped)
 };
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     f4 v = acc[i][2 * c + jj];
-                    if constexpr (EPI == EPI_GELU) v = f4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+                    if constexpr (EPI == EPI_GELU) v = gelu4(v);
                     if constexpr (EPI == EPI_CONV) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
                     *reinterpret_cast<bf16x4a*>(ep + row * 128 + (((i * 2 + (q4 >> 3)) ^ (row & 7)) << 4) + (q4 & 4) * 2) = to_bf16x4(v);
                 }

@@ -811,12 +811,28 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             if ((rc = need(tm, pre + v.name, v.n, &p))) return rc;
             std::memcpy(dst + v.off, p, v.n * sizeof(float));
         }
-        if ((rc = need(tm, pre + "attn.qkv.weight", 3 * C * C, &p))) return rc;
-        pack_linear_image(p, 3 * C, C, dst + vtb::O_WQKV);
+        // norm1 -> qkv and norm2 -> fc1: the LayerNorm's affine part is folded into the linear layer that consumes it, in
+        // double (y = W (gamma * n + beta) + b = (W diag gamma) n + (b + W beta)); the kernels normalise only (vt_blocks.h).
+        auto fold_ln = [&](const char* wname, int out, int o_ln_g, int o_ln_b, int o_bias, int o_w) -> int {
+            const float* W;
+            int rc2 = need(tm, pre + wname, (int64_t)out * C, &W);
+            if (rc2) return rc2;
+            std::vector<float> wf((size_t)out * C);
+            for (int o = 0; o < out; ++o) {
+                double acc = (double)dst[o_bias + o];
+                for (int i = 0; i < C; ++i) {
+                    wf[(size_t)o * C + i] = (float)((double)W[(size_t)o * C + i] * (double)dst[o_ln_g + i]);
+                    acc += (double)W[(size_t)o * C + i] * (double)dst[o_ln_b + i];
+                }
+                dst[o_bias + o] = (float)acc;
+            }
+            pack_linear_image(wf.data(), out, C, dst + o_w);
+            return VT_OK;
+        };
+        if ((rc = fold_ln("attn.qkv.weight", 3 * C, vtb::O_LN1G, vtb::O_LN1B, vtb::O_BQKV, vtb::O_WQKV))) return rc;
         if ((rc = need(tm, pre + "attn.proj.weight", C * C, &p))) return rc;
         pack_linear_image(p, C, C, dst + vtb::O_WPROJ);
-        if ((rc = need(tm, pre + "mlp.fc1.weight", 4 * C * C, &p))) return rc;
-        pack_linear_image(p, 4 * C, C, dst + vtb::O_W1);
+        if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
     }

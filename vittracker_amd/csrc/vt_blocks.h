@@ -98,26 +98,33 @@ __device__ __forceinline__ void interleave_mfma_valu() {
     }
 }
 
-// LayerNorm of one token held as NC operand-image chunks; g/b point at gamma/beta (C floats).
+// LayerNorm of one token held as NC operand-image chunks.  AFFINE = true: g / b point at gamma / beta (C floats) -- the final
+// norm, whose output is the head's input.  AFFINE = false: the normalised token only -- norm1 and norm2 feed a linear layer, and
+// vt_load_weights folds their affine part into it in double precision (W' = W diag(gamma), b' = b + W beta: qkv and fc1), which
+// takes 6 packed multiplies / fmas and 6 LDS reads out of every LayerNorm.
+template <bool AFFINE = true>
 __device__ __forceinline__ void layer_norm_img(const f4 (&x)[NC], f4 (&h)[NC], const float* __restrict__ g,
                                                const float* __restrict__ b, int q) {
-    float s = 0.f;
+    // sums over a token's 48 features: packed adds / fmas over the three chunks first, then one horizontal sum and the two
+    // cross-lane steps (the four lanes sharing lane & 15 hold the token)
+    static_assert(NC == 3, "three feature chunks");
+    const float mean = quad_sum(hsum4((x[0] + x[1]) + x[2])) * (1.0f / C);
+    f4 d[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) s += hsum4(x[c]);
-    const float mean = quad_sum(s) * (1.0f / C);
-    float v = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        f4 d = x[c] - splat4(mean);
-        v += hsum4(d * d);
-    }
-    const float inv = __builtin_amdgcn_rsqf(quad_sum(v) * (1.0f / C) + LN_EPS);   // v_rsq_f32: 1 ulp
+    for (int c = 0; c < NC; ++c) d[c] = x[c] - splat4(mean);
+    const f4 v4 = __builtin_elementwise_fma(d[2], d[2], __builtin_elementwise_fma(d[1], d[1], d[0] * d[0]));
+    const float inv = __builtin_amdgcn_rsqf(quad_sum(hsum4(v4)) * (1.0f / C) + LN_EPS);   // v_rsq_f32: 1 ulp
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const f4 gg = ld4(g + 16 * c + 4 * q), bb = ld4(b + 16 * c + 4 * q);
-        h[c] = (x[c] - splat4(mean)) * splat4(inv) * gg + bb;
+        if constexpr (AFFINE) {
+            const f4 gg = ld4(g + 16 * c + 4 * q), bb = ld4(b + 16 * c + 4 * q);
+            h[c] = d[c] * splat4(inv) * gg + bb;
+        } else {
+            h[c] = d[c] * splat4(inv);
+        }
     }
 }
+__device__ __forceinline__ void layer_norm_plain(const f4 (&x)[NC], f4 (&h)[NC]) { layer_norm_img<false>(x, h, nullptr, nullptr, 0); }
 
 // Weight staging through LDS (WLDS).  Every wave of a workgroup needs every weight tile of a GEMM.
 // Fetched per wave from L2 that is NW x 110 KB per block and workgroup -- with 256 workgroups reading
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 }
             } else if (T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
-                layer_norm_img(x[i], h, S + S_LN1G, S + S_LN1B, q);
+                layer_norm_plain(x[i], h);
                 fstamp();
                 {   // q and k: 6 independent chains, rows = features, cols = tokens (B = h shared)
                     f4 acc[2 * NC];
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         if constexpr (BAL) {
             if (w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
                 f4 h[NC];
-                layer_norm_img(x4, h, S + S_LN1G, S + S_LN1B, q);
+                layer_norm_plain(x4, h);
                 f4 acc[NC];
                 if (g < 2) {
 #pragma unroll
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         auto gelu_group = [&](const f4 (&acc)[HG], f4 (&hd)[NH], int g) {
 #pragma unroll
             for (int j = 0; j < HG; ++j)
-                hd[HG * g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
+                hd[HG * g + j] = gelu4(acc[j]);
         };
         auto fc2 = [&](const f4 (&hd)[NH], int g, f4 (&xo)[NC]) {
             gemm_stage<HG, NC, true, WLDS>(
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         };
         auto mlp_first = [&](int i, int hi) {          // LN2, fc1 (all groups), GELU of groups 0 and 1
             f4 h[NC];
-            layer_norm_img(x[i], h, S + S_LN2G, S + S_LN2B, q);
+            layer_norm_plain(x[i], h);
 #pragma unroll
             for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
             f4 acc0[HG], acc1[HG];
@@ -585,18 +592,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             fstamp();
             fc1(h, 1, acc1);
             gelu_group(acc0, hid[hi], 0);
-            interleave_mfma_valu<12 * HG, 5>();
+            interleave_mfma_valu<12 * HG, 3>();
             __builtin_amdgcn_sched_barrier(0);
             fstamp();
             fc1(h, 2, acc2[hi]);
             gelu_group(acc1, hid[hi], 1);
-            interleave_mfma_valu<12 * HG, 5>();
+            interleave_mfma_valu<12 * HG, 3>();
             __builtin_amdgcn_sched_barrier(0);
         };
         auto mlp_second = [&](int i, int hi) {         // fc2 (+ GELU of group 2 behind its first third)
             fc2(hid[hi], 0, x[i]);
             gelu_group(acc2[hi], hid[hi], 2);
-            interleave_mfma_valu<12 * HG, 5>();
+            interleave_mfma_valu<12 * HG, 3>();
             __builtin_amdgcn_sched_barrier(0);
             fstamp();
             fc2(hid[hi], 1, x[i]);
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q) + Dg[ot * 64 + lane];
                     f4 h[NC];
-                    layer_norm_img(x4, h, S + S_LN2G, S + S_LN2B, q);
+                    layer_norm_plain(x4, h);
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
 #pragma unroll
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         [&](int c) { return h[c]; }, ghid);
 #pragma unroll
                     for (int j = 0; j < NC; ++j)
-                        ghid[j] = f4{gelu_erf(ghid[j].x), gelu_erf(ghid[j].y), gelu_erf(ghid[j].z), gelu_erf(ghid[j].w)};
+                        ghid[j] = gelu4(ghid[j]);
                 }
             }
             stamp();            // fc1 done
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 const int T = w + NW * i;
                 if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                     f4 h[NC];
-                    layer_norm_img(x[i], h, S + S_LN2G, S + S_LN2B, q);
+                    layer_norm_plain(x[i], h);
                     f4 hd[NH];
                     constexpr int G6 = 6;
 #pragma unroll
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         }
 #pragma unroll
                         for (int j = 0; j < G6; ++j)
-                            hd[g + j] = f4{gelu_erf(acc[j].x), gelu_erf(acc[j].y), gelu_erf(acc[j].z), gelu_erf(acc[j].w)};
+                            hd[g + j] = gelu4(acc[j]);
                     }
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void tile_qkv_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < NC; ++c) xr[c] = ld4(src + 16 * c);
     }
-    layer_norm_img(xr, h, P + O_LN1G, P + O_LN1B, q);
+    layer_norm_plain(xr, h);
     {   // q and k: rows = features, cols = tokens (B = h shared)
         f4 acc[2 * NC];
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
     // ---- LayerNorm-2 (redundant), fc1 + GELU of hidden tiles 3g..3g+2, fc2 as four partial sums
     {
         f4 h[NC];
-        layer_norm_img(x, h, P + O_LN2G, P + O_LN2B, q);
+        layer_norm_plain(x, h);
         constexpr int HPW = NH / 4;                      // 3 hidden tiles per wave
         f4 hd[HPW];
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
             },
             [&](int c) { return h[c]; }, hd);
 #pragma unroll
-        for (int j = 0; j < HPW; ++j) hd[j] = f4{gelu_erf(hd[j].x), gelu_erf(hd[j].y), gelu_erf(hd[j].z), gelu_erf(hd[j].w)};
+        for (int j = 0; j < HPW; ++j) hd[j] = gelu4(hd[j]);
         f4 part[NC];
 #pragma unroll
         for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
     // workspace set -- the tile_qkv launch of blocks 1.. disappears.  Wave 0: q, wave 1: k, wave 2: v^T, the chains of tile_qkv_kernel.
     if (Pn != nullptr && g < 3) {
         f4 h[NC];
-        layer_norm_img(x, h, Pn + O_LN1G, Pn + O_LN1B, q);
+        layer_norm_plain(x, h);
         f4 acc[NC];
         if (g < 2) {
 #pragma unroll

@@ -112,21 +112,30 @@ __device__ __forceinline__ float quad_max(float v) {
 __device__ __forceinline__ float hsum4(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hmax4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 exact, <= 5.5e-7 evaluated in fp32):
-// 1 rcp + 1 exp2 + 8 fma instead of the ~35-instruction libm erff; GELU error <= 5e-7 absolute.
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
-    return copysignf(fmaf(-(p * t), e, 1.0f), x);
+// nn.GELU() (exact erf form): 0.5 u (1 + erf(u / sqrt 2)) = u Phi(u), written as
+//     GELU(u) = max(u, 0) - t * 0.5 erfc(t / sqrt 2),   t = |u|
+// (u erf(u / sqrt 2) is even in u), with 0.5 erfc(t / sqrt 2) = 2^(P(t) - 1): P = a degree-6 minimax fit of log2 erfc(t / sqrt 2) on
+// [0, 6.5] weighted by the error it causes in GELU (tools/gelu_fit.py; fit error 8e-8).  t is clamped at 6.5, where the subtracted
+// term is 2e-10.  Max |error| against the exact function, evaluated in fp32: 5.9e-7 (output rounding of fp32 included; the
+// Abramowitz-Stegun 7.1.26 form it replaces: 5.5e-7), below the net's own fp32 noise floor of ~2e-6.
+// Cost per TWO elements: 2 v_min (|u| as a source modifier) + 6 v_pk_fma + 2 v_exp + 2 v_max + 1 v_pk_fma = 13 instructions, one
+// transcendental per element -- against 23 with two transcendentals (rcp + exp2) per element before: GELU was ~45 % of the block
+// kernel's VALU issue.
+__device__ __forceinline__ f2 gelu_pair(f2 u) {
+    const f2 t = {fminf(__builtin_fabsf(u.x), 6.5f), fminf(__builtin_fabsf(u.y), 6.5f)};
+    f2 p = __builtin_elementwise_fma(t, f2{2.992413958e-05f, 2.992413958e-05f}, f2{-7.398738213e-04f, -7.398738213e-04f});
+    p = __builtin_elementwise_fma(p, t, f2{7.977461502e-03f, 7.977461502e-03f});
+    p = __builtin_elementwise_fma(p, t, f2{-5.323818492e-02f, -5.323818492e-02f});
+    p = __builtin_elementwise_fma(p, t, f2{-4.589156874e-01f, -4.589156874e-01f});
+    p = __builtin_elementwise_fma(p, t, f2{-1.151147082e+00f, -1.151147082e+00f});
+    p = __builtin_elementwise_fma(p, t, f2{-1.0f, -1.0f});
+    const f2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    const f2 m = {fmaxf(u.x, 0.0f), fmaxf(u.y, 0.0f)};
+    return __builtin_elementwise_fma(-t, e, m);
 }
-__device__ __forceinline__ float gelu_erf(float u) {
-    // nn.GELU() exact form: 0.5 u (1 + erf(u / sqrt 2))
-    return 0.5f * u * (1.0f + erf_fast(u * 0.70710678118654752440f));
+__device__ __forceinline__ f4 gelu4(f4 u) {
+    const f2 a = gelu_pair(f2{u.x, u.y}), b = gelu_pair(f2{u.z, u.w});
+    return f4{a.x, a.y, b.x, b.y};
 }
 __device__ __forceinline__ float hardswish(float y) {
     return y * fminf(fmaxf(y + 3.0f, 0.0f), 6.0f) * (1.0f / 6.0f);
