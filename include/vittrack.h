@@ -136,6 +136,13 @@ int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const 
  * run as back-to-back graph replays with its state on the device. */
 int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resize_factor_dev, int32_t search_size,
                     int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev);
+/* The same, and what `track()` returns ({"target_bbox", "confidence"}, lib/test/tracker/vit_dist.py:146-148) written as a (B,5)
+ * double record [x, y, w, h, max score] to `record`: device memory, or device-mapped pinned host memory -- then the frame step
+ * ends without a copy kernel or a device -> host copy, the host reads the record after one stream synchronisation.
+ * conf_dev may be NULL (confidence 0). */
+int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float* conf_dev, const double* resize_factor_dev,
+                           int32_t search_size, int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev,
+                           double* record);
 
 /* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,

@@ -23,7 +23,7 @@ print(name, "track() ms:", round((time.perf_counter() - t0) / N * 1e3, 3))
 tu = tr = tg = 0.0
 for i in range(N):
     a = time.perf_counter(); fr = bt._upload(frames[i & 3][None]); b = time.perf_counter()
-    g = bt._chunk_graph(fr.unsqueeze(0))[0]; g.replay(); c = time.perf_counter()
+    g = bt._chunk_graph(fr.unsqueeze(0), to_host=True)[0]; g.replay(); c = time.perf_counter()
     torch.cuda.synchronize(); d = time.perf_counter()
     tu += b - a; tr += c - b; tg += d - c
 print("upload ms", round(tu / N * 1e3, 3), " replay call ms", round(tr / N * 1e3, 3), " wait for GPU ms", round(tg / N * 1e3, 3))

@@ -124,12 +124,12 @@ class BatchedVitTracker:
         if self.frames is not None and any(fr.data_ptr() == f.data_ptr() for f in self.frames):
             # host frames land in one of two fixed device slots: the whole step (crop -> forward -> state update) is one
             # captured graph per slot -- one launch instead of three, no launch gaps inside the step
-            g, boxes, conf, keep = self._chunk_graph(fr.unsqueeze(0))
+            g, rec, host, _ = self._chunk_graph(fr.unsqueeze(0), to_host=sync)
             g.replay()
             if sync:
-                hb, hc = self._read_back(boxes, conf, keep[1])
-                return {"target_bbox": hb[0], "confidence": hc[0]}
-            return {"target_bbox": boxes[0], "confidence": conf[0]}
+                r = self._records(rec, host)
+                return {"target_bbox": r[0, :, :4], "confidence": r[0, :, 4].float()}
+            return {"target_bbox": self.states, "confidence": self.out.conf}
         # a caller-owned device tensor (a new address every call would mean a new capture every call): eager launches
         self.nat.crop(fr, self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
                       out=self.x, resize_factor=self.rf)
@@ -140,20 +140,25 @@ class BatchedVitTracker:
         return {"target_bbox": self.states, "confidence": self.out.conf}
 
     # ---- n frames per launch ------------------------------------------------------------------------------------
-    def _chunk_graph(self, buf):
+    def _chunk_graph(self, buf, to_host=False):
         """The whole tracker step -- crop -> forward -> map back / clip / state update -> record -- for the n frames of `buf`
         (n,B,H,W,3), captured once per frame buffer into ONE graph: no host work and one launch gap per n frames."""
         import torch
         n, _, H, W, _ = buf.shape
-        key = (buf.data_ptr(), n, H, W)
+        to_host = bool(to_host) and self.B * n <= 64
+        key = (buf.data_ptr(), n, H, W, to_host)
         hit = self._chunk_graphs.get(key)
         if hit is not None:
             return hit
         if len(self._chunk_graphs) >= 4:                      # a caller cycling through many buffers: keep the table small
             self._chunk_graphs.pop(next(iter(self._chunk_graphs)))
-        boxes = torch.empty(n, self.B, 4, dtype=torch.float64, device="cuda")
-        conf = torch.empty(n, self.B, device="cuda")
-        host = (torch.empty(n, self.B, 4, dtype=torch.float64).pin_memory(), torch.empty(n, self.B).pin_memory())
+        # Per-frame result records [x, y, w, h, confidence] (float64).  vt_update_state_record writes them where the caller reads
+        # them: small batches straight into PINNED host memory (device-mapped; 40 bytes per sequence over the bus, no copy kernel
+        # and no device -> host copy after the step -- the plugin's one-sequence step), large batches into device memory (read
+        # back on demand).
+        # (to_host: the caller synchronises after every launch -- track(sync=True) of a few sequences)
+        rec = torch.empty(n, self.B, 5, dtype=torch.float64).pin_memory() if to_host else torch.empty(n, self.B, 5, dtype=torch.float64, device="cuda")
+        host = None if to_host else torch.empty(n, self.B, 5, dtype=torch.float64).pin_memory()
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -163,11 +168,10 @@ class BatchedVitTracker:
                 self.nat.crop(buf[i], self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
                               out=self.x, resize_factor=self.rf, stream=cs)
                 self.nat.forward(None, self.x, out=self.out, stream=cs)
-                self.nat.update_state(self.out.hann_boxes, self.rf, self.states, self.params.search_size, H, W, margin=10, stream=cs)
-                boxes[i].copy_(self.states)
-                conf[i].copy_(self.out.conf)
+                self.nat.update_state_record(self.out.hann_boxes, self.out.conf, self.rf, self.states, rec[i], self.params.search_size, H, W,
+                                             margin=10, stream=cs)
         torch.cuda.current_stream().wait_stream(side)
-        self._chunk_graphs[key] = (g, boxes, conf, (buf, host))   # buf: the graph's kernels read it, keep it alive; host: read-back
+        self._chunk_graphs[key] = (g, rec, host, buf)   # buf: the graph's kernels read it, keep it alive
         return self._chunk_graphs[key]
 
     def track_chunk(self, frames, sync: bool = True):
@@ -194,20 +198,20 @@ class BatchedVitTracker:
             buf = self._chunk_buf
         n = int(buf.shape[0])
         self.hw = (int(buf.shape[2]), int(buf.shape[3]))
-        g, boxes, conf, keep = self._chunk_graph(buf)
+        g, rec, host, _ = self._chunk_graph(buf, to_host=sync)
         g.replay()
         self.frame_id += n
         if sync:
-            hb, hc = self._read_back(boxes, conf, keep[1])
-            return {"target_bbox": hb, "confidence": hc}
-        return {"target_bbox": boxes, "confidence": conf}
+            r = self._records(rec, host)
+            return {"target_bbox": r[:, :, :4], "confidence": r[:, :, 4].float()}
+        return {"target_bbox": rec[:, :, :4], "confidence": rec[:, :, 4]}
 
     @staticmethod
-    def _read_back(boxes, conf, host):
-        """Device records -> pinned host tensors with two async copies and one stream synchronisation (a `.cpu()` per tensor
-        goes through pageable memory and synchronises twice); the caller gets its own copies."""
+    def _records(rec, host):
+        """The records of the launch that was just queued, as a CPU tensor the caller owns: one stream synchronisation; records
+        that live in pinned host memory were written by the kernel itself, device records take one async copy first."""
         import torch
-        host[0].copy_(boxes, non_blocking=True)
-        host[1].copy_(conf, non_blocking=True)
+        if host is not None:
+            host.copy_(rec, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        return host[0].clone(), host[1].clone()
+        return (rec if host is None else host).clone()

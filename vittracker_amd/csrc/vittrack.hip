@@ -984,7 +984,17 @@ int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resi
                     int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev) {
     if (!m || !hann_boxes_dev || !resize_factor_dev || !states_dev || B < 1) return fail(VT_ERR_ARG, "bad argument");
     hipLaunchKernelGGL(vtt::update_state_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       hann_boxes_dev, resize_factor_dev, search_size, H, W, margin, B, states_dev);
+                       hann_boxes_dev, resize_factor_dev, search_size, H, W, margin, B, states_dev, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float* conf_dev, const double* resize_factor_dev,
+                           int32_t search_size, int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev,
+                           double* record) {
+    if (!m || !hann_boxes_dev || !resize_factor_dev || !states_dev || !record || B < 1) return fail(VT_ERR_ARG, "bad argument");
+    hipLaunchKernelGGL(vtt::update_state_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       hann_boxes_dev, resize_factor_dev, search_size, H, W, margin, B, states_dev, conf_dev, record);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }

@@ -120,8 +120,11 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
 }
 
 // One thread per sequence.  hann_boxes (B,4) float [cx,cy,w,h] in [0,1]; states (B,4) double in/out.
+// `record` (optional, (B,5) double, device memory or device-mapped pinned host memory): [x, y, w, h, confidence] of the new state --
+// what track() returns; written here, the step needs no copy kernel and no device -> host copy after it.
 __global__ void update_state_kernel(const float* __restrict__ hann_boxes, const double* __restrict__ resize_factor,
-                                    int search_size, int H, int W, int margin, int B, double* __restrict__ states) {
+                                    int search_size, int H, int W, int margin, int B, double* __restrict__ states,
+                                    const float* __restrict__ conf, double* __restrict__ record) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double rf = resize_factor[b];
@@ -146,6 +149,13 @@ __global__ void update_state_kernel(const float* __restrict__ hann_boxes, const 
     states[4 * b + 1] = by1;
     states[4 * b + 2] = fmax((double)margin, bx2 - bx1);
     states[4 * b + 3] = fmax((double)margin, by2 - by1);
+    if (record != nullptr) {
+        record[5 * b + 0] = bx1;
+        record[5 * b + 1] = by1;
+        record[5 * b + 2] = fmax((double)margin, bx2 - bx1);
+        record[5 * b + 3] = fmax((double)margin, by2 - by1);
+        record[5 * b + 4] = conf != nullptr ? (double)conf[b] : 0.0;
+    }
 }
 
 }  // namespace vtt

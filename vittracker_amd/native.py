@@ -23,7 +23,7 @@ SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
-    "vt_set_template", "vt_graph_capture_steps",
+    "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record",
 ]
 
 
@@ -90,6 +90,7 @@ def lib(precision: str = "f32"):
     L.vt_debug_stamps.argtypes = [vp, i32, vp]
     L.vt_crop.argtypes = [vp, vp, i32, i32, vp, C.c_double, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp]
     L.vt_update_state.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.vt_update_state_record.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.vt_set_template.argtypes = [vp, vp, i32, vp]
     if precision == "f32":
         _lib = L
@@ -394,6 +395,22 @@ class Model:
         _check(self._L.vt_update_state(self._h, _ptr(hann_boxes), C.c_void_p(resize_factor.data_ptr()), search_size, H, W,
                                      margin, B, _stream(stream), C.c_void_p(states.data_ptr())), "vt_update_state", self._L)
         return states
+
+    def update_state_record(self, hann_boxes, conf, resize_factor, states, record, search_size, H, W, margin=10, stream=None):
+        """update_state + the (B,5) float64 record [x, y, w, h, confidence] of the new state into `record`: a CUDA tensor or a
+        PINNED host tensor (device-mapped: the kernel writes it over the bus, no copy afterwards)."""
+        import torch
+        B = states.shape[0]
+        if (tuple(states.shape) != (B, 4) or tuple(hann_boxes.shape) != (B, 4) or tuple(resize_factor.shape) != (B,)
+                or states.dtype != torch.float64 or resize_factor.dtype != torch.float64 or not states.is_cuda or not resize_factor.is_cuda):
+            raise VtError(f"update_state_record wants hann_boxes ({B},4) fp32, resize_factor ({B},) fp64 and states ({B},4) fp64 on the GPU")
+        if (tuple(record.shape) != (B, 5) or record.dtype != torch.float64 or not record.is_contiguous()
+                or not (record.is_cuda or record.is_pinned())):
+            raise VtError(f"record must be a contiguous ({B},5) float64 tensor on the GPU or in pinned host memory")
+        _check(self._L.vt_update_state_record(self._h, _ptr(hann_boxes), _ptr(conf), C.c_void_p(resize_factor.data_ptr()), search_size,
+                                            H, W, margin, B, _stream(stream), C.c_void_p(states.data_ptr()),
+                                            C.c_void_p(record.data_ptr())), "vt_update_state_record", self._L)
+        return record
 
     def cal_bbox(self, score, size, offset, stream=None):
         import torch
