@@ -185,6 +185,7 @@ def test_full_batch_is_batch_invariant(geom, B, monkeypatch):
         monkeypatch.setenv(k, "1")
     monkeypatch.setenv("VT_BLOCKS_TILE", "0")
     monkeypatch.setenv("VT_HEAD_SPLIT", "0")
+    monkeypatch.setenv("VT_STEM_STREAM", "1" if geom == "G256" else "0")     # the large-batch stem of each geometry
     tz, tx = GEOMS[geom]
     sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
     z, x = synth.synth_inputs(9, B, tz, tx)

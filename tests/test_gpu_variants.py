@@ -42,6 +42,8 @@ VARIANTS = {
     # the fixtures' batches are small: by default they run the multi-workgroup forms, so the large-batch forms are forced here
     "large_batch_forms_forced": {"VT_STEM_FUSED": "1", "VT_STEM_PIPE": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
     "tile_parallel_blocks_forced": {"VT_BLOCKS_TILE": "1"},
+    "stem_stream_forced": {"VT_STEM_STREAM": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},     # the streaming stem (G256 default at large batches), both geometries
+    "stem_stream_off": {"VT_STEM_STREAM": "0", "VT_STEM_FUSED": "1", "VT_STEM_PIPE": "1"},
     "two_kernel_stem": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "0"},
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},

@@ -21,6 +21,7 @@
 #include "vt_head.h"
 #include "vt_stem.h"
 #include "vt_stem_fused.h"
+#include "vt_stem_stream.h"
 #include "vt_track.h"
 
 namespace {
@@ -97,6 +98,8 @@ struct vt_model {
                            // F = 16: head_seq_kernel (one workgroup per frame runs the three towers in turn, then decodes); auto: B > 176
     int stem_pipe = -1;    // G256: stem_pipe_kernel (layers 1 + 2 per frame) instead of stem_a; auto: B > 176
     int stem_fused = -1;   // G128: stem_fused_kernel (one workgroup per frame) instead of stem_a + stem_b; auto: B > 80
+    int stem_stream = -1;  // stem_stream_kernel (all four layers of a frame streamed band by band through one workgroup) instead of
+                           // stem_pipe + stem_b (G256) / stem_fused (G128); auto: G256 B > 176 (fp32 build)
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
@@ -272,6 +275,33 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
             (T / 4) > 256 || (4 * r4 + 3) > 5 * (256 / (T / 4)))     // stem_b stages <= 5 layer-2 rows per thread and plane
             return fail(VT_ERR_ARG, "unsupported stem band plan for crop side " + std::to_string(T));
     }
+#ifndef VT_F16
+    {   // the streaming form: one workgroup per frame, nothing but token rows leaves the CU
+        const bool g256 = Tx == 256 && Tz == 128, g128 = Tx == 128 && Tz == 64;
+        const bool want_stream = m->stem_stream < 0 ? (g256 && B > 176) : m->stem_stream != 0;
+        const bool diag = m->skip_stem_a != 0 || m->skip_stem_b != 0 || m->dbg_stamps != nullptr;
+        if (want_stream && !diag && (g256 || g128)) {
+            auto go = [&](auto kernel, size_t lds) {
+                hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds, st, z, x, m->stem_w[0].p, m->stem_b[0].p, m->stem_b[1].p,
+                                   m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L,
+                                   m->len_z, m->stem_w2k.p);
+            };
+            if (g256) {
+                constexpr size_t lds = vts::StreamGeo<256, 128>::LDS_BYTES;
+                if (zmode == 0) go(&vts::stem_stream_kernel<256, 128, 0>, lds);
+                else if (zmode == 1) go(&vts::stem_stream_kernel<256, 128, 1>, lds);
+                else go(&vts::stem_stream_kernel<256, 128, 2>, lds);
+            } else {
+                constexpr size_t lds = vts::StreamGeo<128, 64>::LDS_BYTES;
+                if (zmode == 0) go(&vts::stem_stream_kernel<128, 64, 0>, lds);
+                else if (zmode == 1) go(&vts::stem_stream_kernel<128, 64, 1>, lds);
+                else go(&vts::stem_stream_kernel<128, 64, 2>, lds);
+            }
+            HIP_TRY(hipGetLastError());
+            return VT_OK;
+        }
+    }
+#endif
     const bool want_fused = m->stem_fused < 0 ? B > 80 : m->stem_fused != 0;
     const bool want_pipe = m->stem_pipe < 0 ? B > 176 : m->stem_pipe != 0;
     if (want_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
@@ -583,6 +613,14 @@ static hipError_t allow_stem_lds() {
     allow(&vts::stem_fused_kernel<1, false>, lf);
     allow(&vts::stem_fused_kernel<2, false>, lf);
     allow(&vts::stem_fused_kernel<0, true>, lf);
+#ifndef VT_F16
+    allow(&vts::stem_stream_kernel<256, 128, 0>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<256, 128, 1>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<256, 128, 2>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<128, 64, 0>, (int)vts::StreamGeo<128, 64>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<128, 64, 1>, (int)vts::StreamGeo<128, 64>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<128, 64, 2>, (int)vts::StreamGeo<128, 64>::LDS_BYTES);
+#endif
     return e;
 }
 
@@ -654,6 +692,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     m->stem_fused = env_int("VT_STEM_FUSED", -1);
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
+    m->stem_stream = env_int("VT_STEM_STREAM", -1);
     m->head_fused = env_int("VT_HEAD_FUSED", -1);
     m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
