@@ -36,6 +36,9 @@
 #ifndef VB_GEMM_LINE2
 #define VB_GEMM_LINE2 1
 #endif
+#ifndef VB_GEMM_PH8
+#define VB_GEMM_PH8 1        // wide tile: the phase-interleaved schedule with two staggered wave groups (below) instead of one burst per k-tile
+#endif
 
 namespace vbg {
 
@@ -116,12 +119,14 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     //   LINE2: two stages of one 64-deep k-tile; a DMA piece is 8 rows x 128 B, i.e. WHOLE cache lines (half the L2 requests
     //          per byte of the 16-row x 64-byte pieces), XOR-swizzled by row (chunk ^ row): conflict-free ds_read_b128.
     //   PIPE4: four stages of one 32-deep k-step in 16-row x 64-byte pieces (st_16x32), counted vmcnt.
-    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2;
-    constexpr bool PIPE4 = WIDE && !LINE2;
+    constexpr bool PH8 = WIDE && VB_GEMM_PH8;
+    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2 && !PH8;
+    constexpr bool PIPE4 = WIDE && !LINE2 && !PH8;
     constexpr int EP_OFF = 2 * BUF_BYTES;                                           // epilogue staging: 8 waves x 4 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_outer = lane;
     const int wm = w / WN, wn = w % WN;
     const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM, nwg = tiles_m * tiles_n;
     const int grp = blockIdx.y;
@@ -213,6 +218,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     char* const ep = smem + EP_OFF + w * 4096;
     auto epilogue_impl = [&](int m0, int n0, auto check) {
         constexpr bool CHECK = decltype(check)::value;
+        // per-lane epilogue addresses come from a FRESH copy of the lane index: computed from the kernel's own `lane` they are
+        // invariants of the persistent tile loop, hipcc keeps them all in registers across the k-loop and spills fragments instead
+        int lane_e = lane_outer;
+        asm volatile("" : "+v"(lane_e));
+        const int lane = lane_e, l15 = lane & 15, q4 = (lane >> 4) * 4;
         const int mw = m0 + wm * TM * 16, nw = n0 + wn * 64;           // this wave's sub-tile origin
         if constexpr (EPI == EPI_VT) {
             // swapped tile: features on lanes.  Chunk = 16 features x 128 tokens (256-byte rows)
@@ -343,7 +353,174 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     tile_of(vb, m0, n0);
     load_bias(n0, bias_cur);
 
-    if constexpr (LINE2) {
+    if constexpr (PH8) {
+        // ---- Phase-interleaved schedule (cdna_hip_programming.md "The 256^2 8-phase template", rebuilt for this tile).
+        // Two LDS stages of one 64-deep k-tile (64 KiB each) in whole-line pieces as LINE2; a k-tile is FOUR half-panels of
+        // 16 KiB: X rows 0-127 | X rows 128-255 | W rows 0-127 | W rows 128-255, each staged by all 8 waves with 2 DMA
+        // instructions per wave.  A k-tile is four phases; phase = {fragment reads of one accumulator quadrant + ONE half-panel
+        // DMA} | barrier | 16 MFMAs | barrier:
+        //     phase 1   reads X0 (8) + W0 (4)   Q(X0, W0)      stages X-lo (t + 1)
+        //     phase 2   reads W1 (4)            Q(X0, W1)      stages X-hi (t + 1)
+        //     phase 3   reads X1 (8)            Q(X1, W1)      stages W-lo (t + 2)   (every W fragment of tile t is in registers)
+        //     phase 4   (W0 kept)               Q(X1, W0)      stages W-hi (t + 2), then the ONE counted wait of the k-tile:
+        //                                                       vmcnt(4) = all but the two W halves of tile t + 2 have landed
+        // (X0 / X1 = the wave's token tiles 0-3 / 4-7, W0 / W1 = its feature tiles 0-1 / 2-3).  The wave groups wm = 0 (waves 0-3)
+        // and wm = 1 (waves 4-7: the SIMD partners) run one barrier apart: while one group's 16 MFMAs occupy the matrix pipe the
+        // other group issues its LDS reads and DMA.  LDS-DMA data is read one phase after the wait that retires it, behind a
+        // barrier every wave has passed after its own wait; a half-panel is re-staged no earlier than the phase after its last
+        // read, and every phase's reads are retired (lgkmcnt(0)) in front of its first barrier.
+        constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
+        constexpr int NQ = (PX + PW) / NWAVES;                        // 8 DMA instructions per wave and k-tile: i = 2 h, 2 h + 1 for half-panel h
+        static_assert(2 * STAGE_BYTES == EP_OFF && NQ == 8 && TM == 8 && TN == 4, "256 x 256 tile, 2 x 4 waves");
+        const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;
+        unsigned soff[NQ];
+        auto set_sources_p = [&](int m0, int n0) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int p = w + NWAVES * i;
+                if (i < NQ / 2) {
+                    int m = m0 + p * 8 + drow;
+                    m = m < a.M ? m : a.M - 1;
+                    unsigned base;
+                    if constexpr (AMODE == A_CONV) {
+                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        base = (unsigned)(((b * P + y) * P + x) * a.C);
+                    } else {
+                        base = (unsigned)m * (unsigned)a.K;
+                    }
+                    soff[i] = base + dk;
+                } else {
+                    soff[i] = (unsigned)(n0 + (p - PX) * 8 + drow) * (unsigned)a.K + dk;
+                }
+            }
+        };
+        auto issue_half = [&](int kt, int h) {      // half-panel h (0: X-lo, 1: X-hi, 2: W-lo, 3: W-hi) of k-tile kt -> stage kt & 1
+            unsigned kx;
+            if constexpr (AMODE == A_CONV) {
+                const int per_tap = a.C / BK, tap = kt / per_tap, c0 = (kt - tap * per_tap) * BK, r = tap / 3, sx = tap - 3 * r;
+                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
+            } else {
+                kx = (unsigned)kt * BK;
+            }
+            char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * h + ii, p = w + NWAVES * i;
+                const bf16* g = h < 2 ? X + soff[i] + kx : W + soff[i] + (unsigned)kt * BK;
+                glds16(g, st + p * 1024 + lane * 16);
+            }
+        };
+        const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
+        const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
+        const int nk = a.K / BK;
+        bf16x8 fx[4][2], fw0[2][2], fw1[2][2];          // [tile][k-step]
+        auto read_x = [&](const char* st, int half) {
+            const char* xp = st + (wm * TM * 2 + half * 8) * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fx[j][0] = *reinterpret_cast<const bf16x8*>(xp + j * 2048 + fk0);
+                fx[j][1] = *reinterpret_cast<const bf16x8*>(xp + j * 2048 + fk1);
+            }
+        };
+        auto read_w = [&](const char* st, int half, bf16x8 (&fw)[2][2]) {
+            const char* wp = st + (PX + wn * TN * 2 + half * 4) * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fw[i][0] = *reinterpret_cast<const bf16x8*>(wp + i * 2048 + fk0);
+                fw[i][1] = *reinterpret_cast<const bf16x8*>(wp + i * 2048 + fk1);
+            }
+        };
+        auto quadrant = [&](int xh, int wh, const bf16x8 (&fw)[2][2]) {     // 16 MFMAs: token tiles 4 xh .. + 3, feature tiles 2 wh, 2 wh + 1
+            __builtin_amdgcn_s_setprio(1);
+            if (!(a.dbg & 4)) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (EPI == EPI_VT)
+                                acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j][kk], fw[i][kk], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
+                            else
+                                acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][kk], fx[j][kk], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
+                        }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto phase_sync = [&]() {           // retire this phase's fragment reads, then the barrier in front of the MFMAs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto phase_end = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        // tile prologue: k-tile 0 whole, the W halves of k-tile 1 (what phases 3 / 4 of "k-tile -1" would have staged)
+        auto prologue = [&]() {
+            issue_half(0, 0); issue_half(0, 1); issue_half(0, 2); issue_half(0, 3);
+            if (nk > 1) { issue_half(1, 2); issue_half(1, 3); }
+        };
+        set_sources_p((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+        prologue();
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one barrier behind group 0
+        for (;;) {
+            zero_acc();
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* st = smem + (kt & 1) * STAGE_BYTES;
+                // phase 1
+                read_w(st, 0, fw0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_x(st, 0);
+                if (kt + 1 < nk) issue_half(kt + 1, 0);
+                phase_sync();
+                quadrant(0, 0, fw0);
+                phase_end();
+                // phase 2
+                read_w(st, 1, fw1);
+                if (kt + 1 < nk) issue_half(kt + 1, 1);
+                phase_sync();
+                quadrant(0, 1, fw1);
+                phase_end();
+                // phase 3
+                read_x(st, 1);
+                if (kt + 2 < nk) issue_half(kt + 2, 2);
+                phase_sync();
+                quadrant(1, 1, fw1);
+                phase_end();
+                // phase 4: the k-tile's one counted wait -- everything but the two W halves just staged has landed
+                if (kt + 2 < nk) {
+                    issue_half(kt + 2, 3);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                phase_sync();
+                quadrant(1, 0, fw0);
+                phase_end();
+            }
+            // group 0 is one barrier ahead: it waits here for group 1's last phase, then both LDS stages are free
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+            const int cm0 = m0, cn0 = n0;
+            vb += gridDim.x;
+            const bool more = vb < nwg;
+            if (more) {
+                tile_of(vb, m0, n0);
+                set_sources_p((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+                prologue();
+                load_bias(n0, bias_nxt);
+            }
+            if (!(a.dbg & 8)) epilogue(cm0, cn0);
+            if (!more) break;
+            roll_bias();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+        }
+    } else if constexpr (LINE2) {
         // ---- two stages of one 64-deep k-tile in whole-line pieces: [stage][X pieces BM/8 | W pieces BN/8] x 1 KiB,
         // piece = 8 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ r
         constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;

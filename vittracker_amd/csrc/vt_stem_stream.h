@@ -294,7 +294,10 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
             f4 acc[2][1] = {{bv3}, {bv3}};
             auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, J.np2, J.pitch2, J.half2); };
-            vtc::mma_pass<1, 2, NCH3, NCH3>(in, base, w3a, 0, off3, acc);
+#ifndef VT_SS_PIN3
+#define VT_SS_PIN3 false
+#endif
+            vtc::mma_pass<1, 2, NCH3, NCH3, VT_SS_PIN3>(in, base, w3a, 0, off3, acc);
             if (16 * ot3 + 4 * q < 24) {
                 const bool copy_down = J.kb + 1 < J.nb;
 #pragma unroll
