@@ -1,0 +1,49 @@
+#!/bin/bash
+# Round-3 evidence in one box session: rocprofv3 kernel stats (G128, G256, ViT-Base), PMC passes (G128, G256 -> summaries +
+# profiles/pmc_traffic.json; ViT-Base FETCH_SIZE / WRITE_SIZE -> per-step HBM bytes), default bench line.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r3prof; rm -rf $O; mkdir -p $O
+COMMIT=${1:-unknown}
+cd /tmp && export TMPDIR=/tmp
+for g in G128 G256; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$g -- python3 $R/bench.py --geom $g --steps 100 --warmup 20 --no-cpu --no-extra > $O/stats_$g.log 2>&1
+  cp $O/stats_$g/*/*kernel_stats.csv $O/r3_$(echo $g | tr A-Z a-z)_kernel_stats.csv
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vitb -- python3 $R/tools/vitb_time.py > $O/stats_vitb.log 2>&1
+cp $O/stats_vitb/*/*kernel_stats.csv $O/r3_vitb_kernel_stats.csv
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+cd $R
+bash tools/pmc.sh gpurun_out/r3prof/pmc_g128 > /dev/null 2>&1
+bash tools/pmc.sh gpurun_out/r3prof/pmc_g256 --geom G256 > /dev/null 2>&1
+python3 tools/pmc_traffic.py gpurun_out/r3prof/pmc_g128 G128_B256 $COMMIT > /dev/null
+python3 tools/pmc_traffic.py gpurun_out/r3prof/pmc_g256 G256_B256 $COMMIT > /dev/null
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+cp gpurun_out/r3prof/pmc_g128/summary.txt $O/r3_g128_pmc_summary.txt
+cp gpurun_out/r3prof/pmc_g256/summary.txt $O/r3_g256_pmc_summary.txt
+# ViT-Base: HBM bytes per step (two passes: FETCH_SIZE, WRITE_SIZE; 6 replays + 1 capture run in vitb_time.py)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/vitb_$c -- python3 $R/tools/vitb_time.py > $O/vitb_$c.log 2>&1
+done
+python3 - $O <<'P'
+import csv,glob,sys,collections,json
+O=sys.argv[1]
+tot=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(int)
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    for f in glob.glob(f"{O}/vitb_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"]==c:
+                k=r["Kernel_Name"].split("(")[0].replace("void ","")
+                tot[k][c]+=float(r["Counter_Value"]); 
+                if c=="FETCH_SIZE": n[k]+=1
+res={}
+for k,v in tot.items():
+    if "rocclr" in k or "at::" in k: continue
+    res[k]={"dispatches":n[k],"fetch_kib_per_dispatch":round(v["FETCH_SIZE"]/max(1,n[k]),1),"write_kib_per_dispatch":round(v["WRITE_SIZE"]/max(1,n[k]),1),
+            "hbm_bytes_per_dispatch":int((2*v["FETCH_SIZE"]+v["WRITE_SIZE"])*1024/max(1,n[k]))}
+json.dump(res,open(f"{O}/r3_vitb_pmc_traffic.json","w"),indent=1,sort_keys=True)
+print(json.dumps(res,indent=1)[:3000])
+P
+find $O -name "*counter_collection.csv" -size +2000k -delete
+cd $R
+timeout 900 python bench.py > $O/r3_bench.json 2> $O/r3_bench.err; tail -c 600 $O/r3_bench.json
