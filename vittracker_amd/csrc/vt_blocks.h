@@ -295,7 +295,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
             const bool z_tile = ZC && blk == 0 && 16 * T < len_z;       // wave-uniform; compiled out of the default kernel
-            f4* const zc = reinterpret_cast<f4*>(zcache) + (((size_t)b * (len_z >> 4) + T) * 3 * NC) * 64 + lane;
+            // the cache pointer is rebuilt from a fresh copy of the lane index where it is used (block 0 only): as a loop invariant
+            // of the block loop it stayed in registers for the whole kernel (the G256 variant spilled 68 B / lane)
+            int lane_z = lane;
+            if constexpr (ZC) asm volatile("" : "+v"(lane_z));
+            f4* const zc = reinterpret_cast<f4*>(zcache) + (((size_t)b * (len_z >> 4) + T) * 3 * NC) * 64 + lane_z;
             if (T < NOWN && T != dbg_skip_tile && z_tile && zcache_mode == 2) {
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
