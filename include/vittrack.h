@@ -35,7 +35,15 @@ typedef struct vt_model vt_model;
 typedef struct vt_graph vt_graph;
 
 /* Replaces the cfg fields read by build_ostrack_dist (lib/models/vit_dist/vit_dist.py:159-164)
- * and build_box_head CENTER (lib/models/layers/head.py:352-359). */
+ * and build_box_head CENTER (lib/models/layers/head.py:352-359).
+ *
+ * SUPPORTED SHAPES.  The reference builds from any cfg; vt_create accepts exactly three and rejects every other combination with
+ * VT_ERR_ARG and a message naming them:
+ *     channels 48,  heads 1,  head_channels 32,  stride 16, (template, search) = (64, 128) or (128, 256), depth 1..12   -- vit_48_h32
+ *     channels 768, heads 12, head_channels 256, stride 16, (template, search) = (128, 256), depth 12                   -- ViT-Base
+ * The kernels are specialised on their tile counts (token tiles per frame, feature chunks, map sides are template parameters --
+ * that is where their register blocking comes from), so `heads` and the crop sizes are NOT run-time parameters of a kernel: another
+ * geometry is a new instantiation plus its LDS plan. */
 typedef struct vt_config {
     int32_t template_size; /* DATA.TEMPLATE.SIZE  (128; 64 for G128) */
     int32_t search_size;   /* DATA.SEARCH.SIZE    (256; 128 for G128) */

@@ -6,8 +6,9 @@ References: (1) tests/golden/ref_vitb_*.npz = outputs of the reference's own bui
 Tolerance (stated, bf16): operands are rounded to bf16 (8 significand bits, 2^-9 relative) before every contraction,
 accumulation and the residual stream stay in f32.  Observed on MI355X (tools/vitb_diag.py): relative L2 error of the
 residual stream 1.2e-3 after one block, 3.5e-3 after twelve (max abs 3.2e-2 at |x| <= 8.6); maps <= 1.1e-2 (score / size,
-range [0, 1]) and 2.2e-2 (offset); boxes 1.8e-3.  The tests hold ~3x that: rel-L2 1e-2 on activations, 3e-2 / 6e-2 on maps,
-1e-2 on boxes (every fixture's argmax margin is >= 0.03, so no argmax flip is excusable).  north_star's 1e-3 applies to
+range [0, 1]) and 2.2e-2 (offset); boxes 1.9e-3 on fixture s26_b2 and 4.5e-3 on s33_b3 (a box's w / h ARE size-map values).  The
+tests hold 2x the observed (round 3; 3x before): rel-L2 7e-3 on activations, 2.2e-2 / 4.4e-2 on maps, 9e-3 on boxes (every fixture's
+argmax margin is >= 0.03, so no argmax flip is excusable).  north_star's 1e-3 applies to
 the fp32 vit_48 path, not to this bf16 one."""
 import os
 
@@ -18,9 +19,9 @@ from conftest import load_vitb_case, vitb_golden_files
 
 pytestmark = pytest.mark.gpu
 
-TOL_REL = 1e-2
-TOL_MAP = {"score_map": 3e-2, "size_map": 3e-2, "offset_map": 6e-2}
-TOL_BOX = 1e-2
+TOL_REL = 7e-3
+TOL_MAP = {"score_map": 2.2e-2, "size_map": 2.2e-2, "offset_map": 4.4e-2}
+TOL_BOX = 9e-3
 
 
 def _model(sd, B):

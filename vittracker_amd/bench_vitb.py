@@ -19,6 +19,25 @@ def macs():
             "head": Lx * (3 * 9 * (C * W + W * W // 2 + W * W // 8 + W * W // 32) + 5 * W // 8)}
 
 
+def pmc_traffic_blocks():
+    """HBM bytes per step of the transformer-block kernels (GEMMs, attention, LayerNorm) from the committed rocprofv3 --pmc passes
+    (profiles/r3_vitb_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE), quoted only while the ViT-Base kernel
+    sources still hash to what the entry was measured on.  Returns (bytes or None, note)."""
+    try:
+        import bench as B0
+        t = json.load(open(os.path.join(ROOT, "profiles", "r3_vitb_pmc_traffic.json")))
+        h = B0.kernel_source_hash(prefixes=("vb_", "vitb"))
+        if t.get("_kernel_source_hash") != h:
+            return None, f"committed PMC measurement is stale (taken on kernel sources {t.get('_kernel_source_hash')}, now {h})"
+        n = int(t["_forwards_in_run"])
+        keys = [k for k in t if not k.startswith("_") and ("attn_kernel" in k or "layernorm" in k or
+                                                             any(f"gemm_kernel<256, 256, 2, 4, 0, {e}>" in k for e in (1, 2, 3, 5)))]
+        tot = sum(t[k]["dispatches"] * t[k]["hbm_bytes_per_dispatch"] for k in keys) // n
+        return int(tot), f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE summed over the block kernels of one step, measured at commit {t.get('_commit', '?')}"
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profiles/r3_vitb_pmc_traffic.json: {e}"
+
+
 def run(a):
     print(json.dumps(measure(a)), flush=True)
 
@@ -49,7 +68,7 @@ def measure(a):
     graph.launch(s); s.synchronize()
     errs = {k: float(np.abs(getattr(out, k)[:nb].cpu().numpy() - g[k][:nb]).max()) for k in ("score_map", "size_map", "offset_map")}
     errs["pred_boxes"] = float(np.abs(out.pred_boxes[:nb].cpu().numpy() - g["pred_boxes"][:nb, 0]).max())
-    if not (errs["score_map"] < 3e-2 and errs["size_map"] < 3e-2 and errs["offset_map"] < 6e-2 and errs["pred_boxes"] < 1e-2):
+    if not (errs["score_map"] < 2.2e-2 and errs["size_map"] < 2.2e-2 and errs["offset_map"] < 4.4e-2 and errs["pred_boxes"] < 4e-3):     # tests/test_gpu_vitb.py
         raise SystemExit(f"bench.py --config vitb: the timed configuration disagrees with the reference fixture: {errs}")
     zd[:nb].copy_(zs); xd[:nb].copy_(xs)
     torch.cuda.synchronize()
@@ -94,10 +113,11 @@ def measure(a):
         t_blocks = e0.elapsed_time(e1) * 1e3 / iters
         flop_blocks = 2 * mac["blocks"] * B
         ach = flop_blocks / (t_blocks * 1e-6) / 1e12
+        traffic, tnote = pmc_traffic_blocks()
         line["roofline"] = {"kernel": "transformer blocks (12 x {LN, qk / v GEMM, attention, proj GEMM, LN, fc1 GEMM, fc2 GEMM})",
                             "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "flop_per_launch": flop_blocks,
-                            "avg_launch_us": round(t_blocks, 1)}
+                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
+                            "flop_per_launch": flop_blocks, "avg_launch_us": round(t_blocks, 1)}
     graph = None
     m.close()
     return line
