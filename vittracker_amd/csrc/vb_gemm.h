@@ -82,7 +82,7 @@ struct Args {
                           // 32 concurrent tiles of an XCD are ~rb rows x 32 / rb columns); 0 / 1 = row-major
     int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
                           // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
-                          // 4 = no MFMAs, 8 = no epilogue
+                          // 4 = no MFMAs, 8 = no epilogue, 16 = no W staging, 32 = no X staging (wide tile)
 };
 
 // The epilogue staging area is written and read back through differently typed pointers by the same wave: the accesses
@@ -403,6 +403,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 kx = (unsigned)kt * BK;
             }
             char* st = smem + (kt & 1) * STAGE_BYTES;
+            if ((a.dbg & 16) && h >= 2) return;          // timing experiments: no W staging / no X staging (wrong results)
+            if ((a.dbg & 32) && h < 2) return;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * h + ii, p = w + NWAVES * i;
