@@ -189,3 +189,24 @@ def test_build_ostrack_model_level_surface():
     np.testing.assert_allclose(out["pred_boxes"].cpu().numpy()[:, 0], g["pred_boxes"][:, 0], atol=TOL_BOX, rtol=0)
     with pytest.raises(NotImplementedError):
         net(template=torch.from_numpy(z).cuda(), search=torch.from_numpy(x).cuda(), ce_template_mask=torch.zeros(1))
+
+
+@pytest.mark.parametrize("B", [5, 96])
+def test_vitb_replays_are_bit_identical(B):
+    """Race screen of the GEMM's phase schedule (LDS-DMA data read behind counted waits and barriers, two wave groups one barrier
+    apart): many replays of the captured step on fixed inputs equal the first one bit for bit (tools/stress_vitb.py runs more)."""
+    import torch
+    from vittracker_amd import synth
+    sd = synth.synth_vitb_state_dict(26)
+    m = _model(sd, B)
+    z, x = synth.synth_inputs(B + 3, B, 128, 256)
+    graph, out = m.capture(torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda())
+    graph.launch()
+    torch.cuda.synchronize()
+    ref = {k: getattr(out, k).clone() for k in ("score_map", "size_map", "offset_map", "pred_boxes")}
+    for it in range(40):
+        graph.launch()
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+            for k, v in ref.items():
+                assert torch.equal(getattr(out, k), v), (it, k)
