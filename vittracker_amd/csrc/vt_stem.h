@@ -237,8 +237,10 @@ __device__ __forceinline__ JobA make_job_a(const CropA& c, int b, int k, int map
     return j;
 }
 // value of the previous lane (lane 0: 0) in VALU latency: v_mov_b32_dpp wave_shr:1
+// (v_mov_b32_dpp with no `old` operand: lanes without a source -- lane 0 -- read 0; with update_dpp's `old` hipcc initialises the
+// destination with a v_mov in front of every call)
 __device__ __forceinline__ float lane_left(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 
 __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a2_kernel(

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             float (&nxt)[18] = (sec & 1) ? wa : wb;
             if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
             const int r = sec / 3, c = sec % 3;
-            const f4 vv = r == 0 ? v[r][c] * splat4(keep0) : v[r][c];
+            const f4 vv = (r == 0 && J.p0 == 0) ? v[r][c] * splat4(keep0) : v[r][c];     // kernel row 0 is the zero padding only in the band at the image top
             const float left = lane_left(vv.w);               // a wave starts at a row start: lane 0 has qp = 0
             const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
@@ -342,10 +342,11 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         // The next band's input is requested one interval ahead: by the four waves without layer-2 work (gw >= 4) at the start of
         // the interval, by the four that run layer 2 right after it (its accumulators, double-buffered operands and the nine
         // prefetched float4 together do not fit in 128 registers; layer 2 takes a third of the interval, the rest covers the loads).
+        // (ONE fetch site: layer 2 is a no-op for the waves with gw >= 4, so "after layer 2" is "at once" for them; two sites made
+        // hipcc give the prefetch two register sets and merge them with 18 v_mov_b64 per band)
         auto l2_and_fetch = [&](const auto& J2, bool run2, const auto& Jn, bool run_f) {
-            if (run_f && gw >= 4) fetch(Jn, v);
             if (run2) layer2(J2);
-            if (run_f && gw < 4) fetch(Jn, v);
+            if (run_f) fetch(Jn, v);
         };
         if (grp == 0) {
             if (do_z) layer1(bz, v);                    stamp(); __syncthreads(); stamp();   // 0: L1(z)
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
             float (&nxt)[18] = (sec & 1) ? wa : wb;
             if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
             const int r = sec / 3, c = sec % 3;
-            const f4 vv = r == 0 ? v[r][c] * splat4(keep0) : v[r][c];
+            const f4 vv = (r == 0 && J.p0 == 0) ? v[r][c] * splat4(keep0) : v[r][c];     // only the band at the image top has a padding row
             const float left = lane_left(vv.w);
             const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
                 float (&nxt)[18] = (sec & 1) ? wa : wb;
                 if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
                 const int r = sec / 3, c = sec % 3;
-                const f4 vv = r == 0 ? v[r][c] * splat4(keep0) : v[r][c];
+                const f4 vv = (r == 0 && J.kb == 0) ? v[r][c] * splat4(keep0) : v[r][c];      // only the band at the top of a crop has a padding row
                 const float left = lane_left(vv.w);                 // a wave starts at a row start: lane 0 has qp = 0
                 const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
