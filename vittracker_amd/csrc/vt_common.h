@@ -118,20 +118,22 @@ __device__ __forceinline__ float hmax4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fma
 // [0, 6.5] weighted by the error it causes in GELU (tools/gelu_fit.py; fit error 8e-8).  t is clamped at 6.5, where the subtracted
 // term is 2e-10.  Max |error| against the exact function, evaluated in fp32: 5.9e-7 (output rounding of fp32 included; the
 // Abramowitz-Stegun 7.1.26 form it replaces: 5.5e-7), below the net's own fp32 noise floor of ~2e-6.
-// Cost per TWO elements: 2 v_min (|u| as a source modifier) + 6 v_pk_fma + 2 v_exp + 2 v_max + 1 v_pk_fma = 13 instructions, one
+// Cost per TWO elements: 2 v_max (-|u| as source modifiers) + 6 v_pk_fma + 2 v_exp + 2 v_max + 1 v_pk_fma = 13 instructions, one
 // transcendental per element -- against 23 with two transcendentals (rcp + exp2) per element before: GELU was ~45 % of the block
 // kernel's VALU issue.
 __device__ __forceinline__ f2 gelu_pair(f2 u) {
-    const f2 t = {fminf(__builtin_fabsf(u.x), 6.5f), fminf(__builtin_fabsf(u.y), 6.5f)};
-    f2 p = __builtin_elementwise_fma(t, f2{2.992413958e-05f, 2.992413958e-05f}, f2{-7.398738213e-04f, -7.398738213e-04f});
-    p = __builtin_elementwise_fma(p, t, f2{7.977461502e-03f, 7.977461502e-03f});
-    p = __builtin_elementwise_fma(p, t, f2{-5.323818492e-02f, -5.323818492e-02f});
-    p = __builtin_elementwise_fma(p, t, f2{-4.589156874e-01f, -4.589156874e-01f});
-    p = __builtin_elementwise_fma(p, t, f2{-1.151147082e+00f, -1.151147082e+00f});
-    p = __builtin_elementwise_fma(p, t, f2{-1.0f, -1.0f});
+    // nt = -t = max(-|u|, -6.5): negation and absolute value are source modifiers of the v_max; the polynomial is written in nt (odd
+    // coefficients change sign) and the last step is fma(nt, e, max(u, 0)) -- no separate negation anywhere
+    const f2 nt = {__builtin_fmaxf(-__builtin_fabsf(u.x), -6.5f), __builtin_fmaxf(-__builtin_fabsf(u.y), -6.5f)};
+    f2 p = __builtin_elementwise_fma(nt, f2{2.992413958e-05f, 2.992413958e-05f}, f2{7.398738213e-04f, 7.398738213e-04f});
+    p = __builtin_elementwise_fma(p, nt, f2{7.977461502e-03f, 7.977461502e-03f});
+    p = __builtin_elementwise_fma(p, nt, f2{5.323818492e-02f, 5.323818492e-02f});
+    p = __builtin_elementwise_fma(p, nt, f2{-4.589156874e-01f, -4.589156874e-01f});
+    p = __builtin_elementwise_fma(p, nt, f2{1.151147082e+00f, 1.151147082e+00f});
+    p = __builtin_elementwise_fma(p, nt, f2{-1.0f, -1.0f});
     const f2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
     const f2 m = {fmaxf(u.x, 0.0f), fmaxf(u.y, 0.0f)};
-    return __builtin_elementwise_fma(-t, e, m);
+    return __builtin_elementwise_fma(nt, e, m);
 }
 __device__ __forceinline__ f4 gelu4(f4 u) {
     const f2 a = gelu_pair(f2{u.x, u.y}), b = gelu_pair(f2{u.z, u.w});
