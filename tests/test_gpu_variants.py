@@ -104,3 +104,34 @@ def test_graph_chains_match_eager(chains):
     env = dict(os.environ, VT_GRAPH_CHAINS=chains)
     r = subprocess.run([sys.executable, "-c", CHAINS_CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+
+
+# ViT-Base (vitb.hip): the chains work on frame slices of every workspace (tower-major head buffers keep the batch's stride) and
+# their persistent GEMMs launch on a share of the CUs; results are per-row, so the graph must equal the eager step bit for bit.
+VITB_CHAINS_CODE = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import torch
+from vittracker_amd import native, synth
+for B in (5, 24):
+    m = native.Model(128, 256, channels=768, heads=12, depth=12, head_channels=256, max_batch=B + 3)
+    m.load_state_dict(synth.synth_vitb_state_dict(26))
+    z, x = synth.synth_inputs(11, B, 128, 256)
+    zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+    e = m.forward(zd, xd)
+    ref = {k: getattr(e, k).clone() for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")}
+    g, out = m.capture(zd, xd)
+    for _ in range(2):
+        g.launch(); torch.cuda.synchronize()
+        for k, v in ref.items():
+            assert torch.equal(getattr(out, k), v), (B, k)
+    m.close()
+print("OK")
+""" % {"root": ROOT}
+
+
+@pytest.mark.parametrize("chains", ["2", "3"])
+def test_vitb_graph_chains_match_eager(chains):
+    env = dict(os.environ, VT_GRAPH_CHAINS=chains)
+    r = subprocess.run([sys.executable, "-c", VITB_CHAINS_CODE], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])

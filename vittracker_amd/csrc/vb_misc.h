@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void feat_to_map_kernel(const float* __restric
 // w5: [5][CW] f32 rows = ctr, offset0, offset1, size0, size1;  b5: [5].  One thread per pixel.
 template <int CW>
 __global__ __launch_bounds__(256) void conv5_kernel(const bf16* __restrict__ t4, const float* __restrict__ w5,
-                                                    const float* __restrict__ b5, int npix_total, int FF,
+                                                    const float* __restrict__ b5, int npix_total, int FF, size_t tower_stride,
                                                     float* __restrict__ score, float* __restrict__ size, float* __restrict__ offset) {
     __shared__ float sw[5 * CW + 5];
     for (int i = threadIdx.x; i < 5 * CW + 5; i += 256) sw[i] = i < 5 * CW ? w5[i] : b5[i - 5 * CW];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv5_kernel(const bf16* __restrict__ t4,
     for (int j = 0; j < 5; ++j) o[j] = sw[5 * CW + j];
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw) {
-        const bf16* src = t4 + ((size_t)tw * npix_total + p) * CW;
+        const bf16* src = t4 + (size_t)tw * tower_stride + (size_t)p * CW;    // tower_stride: elements between towers
 #pragma unroll
         for (int c8 = 0; c8 < CW / 8; ++c8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c8 * 8);

@@ -108,7 +108,7 @@ int num_cus() {
 inline int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E) {
+int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E, int cus = 0) {
     if (a.M < 1 || a.K % vbg::BK != 0 || a.N % 8 != 0)
         return E.fail(VT_ERR_ARG, "gemm shape: K must be a multiple of 64 and N of 8 (got M=" + std::to_string(a.M) + " N=" +
                                       std::to_string(a.N) + " K=" + std::to_string(a.K) + ")");
@@ -122,7 +122,9 @@ int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E) {
     }
     // persistent workgroups: one per CU, each walks tiles blockIdx.x, blockIdx.x + grid, ...
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const int tiles = std::min(ntiles, std::max(8, num_cus() / groups / 8 * 8));
+    static const int max_cus = env_int("VB_MAX_CUS", 0);      // experiment hook: persistent grid of at most this many workgroups
+    if (max_cus > 0) cus = cus > 0 ? std::min(cus, max_cus) : max_cus;
+    const int tiles = std::min(ntiles, std::max(8, (cus > 0 ? std::min(cus, num_cus()) : num_cus()) / groups / 8 * 8));
     constexpr int lds = vbg::lds_bytes<BM, BN>();
     hipLaunchKernelGGL((vbg::gemm_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(tiles, groups), dim3(512), lds, st, ad);
     VB_HIP(hipGetLastError());
@@ -134,9 +136,9 @@ hipError_t allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int run_layernorm(VbModel* m, const float* g, const float* b, int B, hipStream_t st, bf16* xn, bf16* map, float* feat, const Err& E) {
+int run_layernorm(const float* resid, const float* g, const float* b, int B, hipStream_t st, bf16* xn, bf16* map, float* feat, const Err& E) {
     const int M = B * L;
-    hipLaunchKernelGGL((vbm::layernorm_kernel<C>), dim3((M + 3) / 4), dim3(256), 0, st, m->resid.p, g, b, LN_EPS, M, L, LZ, F, xn, map, feat);
+    hipLaunchKernelGGL((vbm::layernorm_kernel<C>), dim3((M + 3) / 4), dim3(256), 0, st, resid, g, b, LN_EPS, M, L, LZ, F, xn, map, feat);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }
@@ -300,90 +302,117 @@ static int check(VbModel* m, int B, const Err& E) {
     return VT_OK;
 }
 
-int stem(VbModel* m, const float* z, const float* x, int B, hipStream_t st, float* tokens_out, std::string* err) {
-    const Err E{err};
-    int rc = check(m, B, E);
-    if (rc) return rc;
-    const int M = B * L;
-    const size_t items = (size_t)M * 96;
-    hipLaunchKernelGGL(vbm::patchify_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 16384)), dim3(256), 0, st, z, x, m->xn.p, B,
-                       128, 256);
-    VB_HIP(hipGetLastError());
-    vbg::Args a{};
-    a.X = m->xn.p; a.W = m->wpatch.p; a.bias = m->bpatch.p; a.resid = m->resid.p; a.pos = m->pos.p;
-    a.M = M; a.N = C; a.K = PATCH_K; a.L = L;
-    if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_PATCH>(a, 1, st, E))) return rc;
-    if (tokens_out) VB_HIP(hipMemcpyAsync(tokens_out, m->resid.p, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
+static int check_slice(VbModel* m, int B, const Slice* sl, const Err& E) {
+    if (sl && (sl->Btot < 1 || sl->Btot > m->maxB || sl->f0 + (size_t)B > (size_t)sl->Btot))
+        return E.fail(VT_ERR_STATE, "frame slice outside the batch");
     return VT_OK;
 }
 
-int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t st, float* feat_out, float* resid_out, std::string* err) {
+int stem(VbModel* m, const float* z, const float* x, int B, hipStream_t st, float* tokens_out, std::string* err, const Slice* sl) {
     const Err E{err};
     int rc = check(m, B, E);
-    if (rc) return rc;
+    if (rc || (rc = check_slice(m, B, sl, E))) return rc;
     const int M = B * L;
-    if (nblocks < 0 || nblocks > m->depth) nblocks = m->depth;
-    if (tokens_in && tokens_in != m->resid.p)
-        VB_HIP(hipMemcpyAsync(m->resid.p, tokens_in, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
-    for (int i = 0; i < nblocks; ++i) {
-        const BlockW& b = m->blk[i];
-        if ((rc = run_layernorm(m, b.ln1g.p, b.ln1b.p, B, st, m->xn.p, nullptr, nullptr, E))) return rc;
-        vbg::Args a{};
-        a.X = m->xn.p; a.W = b.wqkv.p; a.bias = b.bqkv.p; a.out = m->qk.p;          // q | k: rows 0 .. 2C of W_qkv
-        a.M = M; a.N = 2 * C; a.K = C; a.ldo = 2 * C; a.rb = 4;    // 4 tile rows x 8 columns per XCD: measured 4 % faster than row-major
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_BF16>(a, 1, st, E))) return rc;
-        vbg::Args v{};
-        v.X = m->xn.p; v.W = b.wqkv.p + (size_t)2 * C * C; v.bias = b.bqkv.p + 2 * C; v.vt = m->vt.p;   // v: rows 2C .. 3C, stored transposed
-        v.M = M; v.N = C; v.K = C; v.L = L;
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_VT>(v, 1, st, E))) return rc;
-        constexpr int attn_lds = vba::Geo<L, HD>::LDS_BYTES;
-        hipLaunchKernelGGL((vba::attn_kernel<L, HD>), dim3(B * HEADS), dim3(256), attn_lds, st, m->qk.p, m->vt.p, m->ao.p, HEADS);
-        VB_HIP(hipGetLastError());
-        vbg::Args p{};
-        p.X = m->ao.p; p.W = b.wproj.p; p.bias = b.bproj.p; p.resid = m->resid.p; p.M = M; p.N = C; p.K = C;
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(p, 1, st, E))) return rc;
-        if ((rc = run_layernorm(m, b.ln2g.p, b.ln2b.p, B, st, m->xn.p, nullptr, nullptr, E))) return rc;
-        vbg::Args f1{};
-        f1.X = m->xn.p; f1.W = b.w1.p; f1.bias = b.b1.p; f1.out = m->hid.p; f1.M = M; f1.N = HID; f1.K = C; f1.ldo = HID; f1.rb = 4;
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_GELU>(f1, 1, st, E))) return rc;
-        vbg::Args f2{};
-        f2.X = m->hid.p; f2.W = b.w2.p; f2.bias = b.b2.p; f2.resid = m->resid.p; f2.M = M; f2.N = C; f2.K = HID;
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(f2, 1, st, E))) return rc;
-    }
-    if (resid_out) VB_HIP(hipMemcpyAsync(resid_out, m->resid.p, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
-    return run_layernorm(m, m->ng.p, m->nb.p, B, st, nullptr, m->map0.p, feat_out, E);
+    const size_t r0 = (sl ? sl->f0 : 0) * L;          // first token row of the slice
+    const int cus = sl ? sl->cus : 0;
+    bf16* const xn = m->xn.p + r0 * C;
+    float* const resid = m->resid.p + r0 * C;
+    const size_t items = (size_t)M * 96;
+    hipLaunchKernelGGL(vbm::patchify_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 16384)), dim3(256), 0, st, z, x, xn, B,
+                       128, 256);
+    VB_HIP(hipGetLastError());
+    vbg::Args a{};
+    a.X = xn; a.W = m->wpatch.p; a.bias = m->bpatch.p; a.resid = resid; a.pos = m->pos.p;
+    a.M = M; a.N = C; a.K = PATCH_K; a.L = L;
+    if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_PATCH>(a, 1, st, E, cus))) return rc;
+    if (tokens_out) VB_HIP(hipMemcpyAsync(tokens_out, resid, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
+    return VT_OK;
 }
 
-int head(VbModel* m, const float* feat_in, int B, hipStream_t st, float* score, float* size, float* offset, std::string* err) {
+int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t st, float* feat_out, float* resid_out, std::string* err,
+           const Slice* sl) {
     const Err E{err};
     int rc = check(m, B, E);
-    if (rc) return rc;
+    if (rc || (rc = check_slice(m, B, sl, E))) return rc;
+    const int M = B * L;
+    const size_t f0 = sl ? sl->f0 : 0, r0 = f0 * L;
+    const int cus = sl ? sl->cus : 0;
+    bf16* const xn = m->xn.p + r0 * C;
+    float* const resid = m->resid.p + r0 * C;
+    bf16* const qk = m->qk.p + r0 * 2 * C;
+    bf16* const vt = m->vt.p + r0 * C;                 // [frame][C][L]
+    bf16* const ao = m->ao.p + r0 * C;
+    bf16* const hid = m->hid.p + r0 * HID;
+    bf16* const map0 = m->map0.p + f0 * (size_t)(F + 2) * (F + 2) * C;
+    if (nblocks < 0 || nblocks > m->depth) nblocks = m->depth;
+    if (tokens_in && tokens_in != resid)
+        VB_HIP(hipMemcpyAsync(resid, tokens_in, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < nblocks; ++i) {
+        const BlockW& b = m->blk[i];
+        if ((rc = run_layernorm(resid, b.ln1g.p, b.ln1b.p, B, st, xn, nullptr, nullptr, E))) return rc;
+        vbg::Args a{};
+        a.X = xn; a.W = b.wqkv.p; a.bias = b.bqkv.p; a.out = qk;          // q | k: rows 0 .. 2C of W_qkv
+        a.M = M; a.N = 2 * C; a.K = C; a.ldo = 2 * C; a.rb = 4;    // 4 tile rows x 8 columns per XCD: measured 4 % faster than row-major
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_BF16>(a, 1, st, E, cus))) return rc;
+        vbg::Args v{};
+        v.X = xn; v.W = b.wqkv.p + (size_t)2 * C * C; v.bias = b.bqkv.p + 2 * C; v.vt = vt;   // v: rows 2C .. 3C, stored transposed
+        v.M = M; v.N = C; v.K = C; v.L = L;
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_VT>(v, 1, st, E, cus))) return rc;
+        constexpr int attn_lds = vba::Geo<L, HD>::LDS_BYTES;
+        hipLaunchKernelGGL((vba::attn_kernel<L, HD>), dim3(B * HEADS), dim3(256), attn_lds, st, qk, vt, ao, HEADS);
+        VB_HIP(hipGetLastError());
+        vbg::Args p{};
+        p.X = ao; p.W = b.wproj.p; p.bias = b.bproj.p; p.resid = resid; p.M = M; p.N = C; p.K = C;
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(p, 1, st, E, cus))) return rc;
+        if ((rc = run_layernorm(resid, b.ln2g.p, b.ln2b.p, B, st, xn, nullptr, nullptr, E))) return rc;
+        vbg::Args f1{};
+        f1.X = xn; f1.W = b.w1.p; f1.bias = b.b1.p; f1.out = hid; f1.M = M; f1.N = HID; f1.K = C; f1.ldo = HID; f1.rb = 4;
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_GELU>(f1, 1, st, E, cus))) return rc;
+        vbg::Args f2{};
+        f2.X = hid; f2.W = b.w2.p; f2.bias = b.b2.p; f2.resid = resid; f2.M = M; f2.N = C; f2.K = HID;
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(f2, 1, st, E, cus))) return rc;
+    }
+    if (resid_out) VB_HIP(hipMemcpyAsync(resid_out, resid, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
+    return run_layernorm(resid, m->ng.p, m->nb.p, B, st, nullptr, map0, feat_out, E);
+}
+
+int head(VbModel* m, const float* feat_in, int B, hipStream_t st, float* score, float* size, float* offset, std::string* err,
+         const Slice* sl) {
+    const Err E{err};
+    int rc = check(m, B, E);
+    if (rc || (rc = check_slice(m, B, sl, E))) return rc;
+    const size_t f0 = sl ? sl->f0 : 0;
+    const long long Bt = sl ? sl->Btot : B;              // tower-major buffers: [tower][Bt frames]...
+    const int cus = sl ? sl->cus : 0;
+    bf16* const map0 = m->map0.p + f0 * (size_t)(F + 2) * (F + 2) * C;
     if (feat_in) {
         const size_t items = (size_t)B * LX * (C / 4);
         hipLaunchKernelGGL(vbm::feat_to_map_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 16384)), dim3(256), 0, st, feat_in,
-                           m->map0.p, B, F, C);
+                           map0, B, F, C);
         VB_HIP(hipGetLastError());
     }
     const int M = B * LX;
     const long long P2 = (long long)(F + 2) * (F + 2);
     {   // conv1 of the three towers as one GEMM: N = 3 x 256, K = 9 x 768
         vbg::Args a{};
-        a.X = m->map0.p; a.W = m->wc[0].p; a.bias = m->bc[0].p; a.out = m->map1.p;
+        a.X = map0; a.W = m->wc[0].p; a.bias = m->bc[0].p; a.out = m->map1.p + f0 * (size_t)P2 * HEAD_CH[1];
         a.M = M; a.N = 3 * HEAD_CH[1]; a.K = 9 * HEAD_CH[0]; a.ldo = HEAD_CH[1]; a.C = HEAD_CH[0]; a.F = F; a.out_padded = 1;
-        a.n_split = HEAD_CH[1]; a.gOut = (long long)B * P2 * HEAD_CH[1];
-        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_CONV, vbg::EPI_CONV>(a, 1, st, E))) return rc;
+        a.n_split = HEAD_CH[1]; a.gOut = Bt * P2 * HEAD_CH[1];
+        if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_CONV, vbg::EPI_CONV>(a, 1, st, E, cus))) return rc;
     }
-    bf16* maps[4] = {m->map1.p, m->map2.p, m->map3.p, m->t4.p};
+    bf16* maps[4] = {m->map1.p + f0 * (size_t)P2 * HEAD_CH[1], m->map2.p + f0 * (size_t)P2 * HEAD_CH[2],
+                     m->map3.p + f0 * (size_t)P2 * HEAD_CH[3], m->t4.p + f0 * (size_t)LX * HEAD_CH[4]};
     for (int li = 1; li < 4; ++li) {   // conv2..4: one launch per layer, blockIdx.y = tower
         const int cin = HEAD_CH[li], cout = HEAD_CH[li + 1], rows = cout < 64 ? 64 : cout;
         vbg::Args a{};
         a.X = maps[li - 1]; a.W = m->wc[li].p; a.bias = m->bc[li].p; a.out = maps[li];
         a.M = M; a.N = cout; a.K = 9 * cin; a.ldo = cout; a.C = cin; a.F = F; a.out_padded = li < 3;
-        a.gX = (long long)B * P2 * cin; a.gW = (long long)rows * 9 * cin; a.gBias = cout;
-        a.gOut = li < 3 ? (long long)B * P2 * cout : (long long)M * cout;
-        if ((rc = launch_gemm<256, 64, 8, 1, vbg::A_CONV, vbg::EPI_CONV>(a, 3, st, E))) return rc;
+        a.gX = Bt * P2 * cin; a.gW = (long long)rows * 9 * cin; a.gBias = cout;
+        a.gOut = li < 3 ? Bt * P2 * cout : Bt * LX * cout;
+        if ((rc = launch_gemm<256, 64, 8, 1, vbg::A_CONV, vbg::EPI_CONV>(a, 3, st, E, cus))) return rc;
     }
-    hipLaunchKernelGGL((vbm::conv5_kernel<32>), dim3((M + 255) / 256), dim3(256), 0, st, m->t4.p, m->w5.p, m->b5.p, M, LX, score, size, offset);
+    hipLaunchKernelGGL((vbm::conv5_kernel<32>), dim3((M + 255) / 256), dim3(256), 0, st, maps[3], m->w5.p, m->b5.p, M, LX,
+                       (size_t)(Bt * LX * HEAD_CH[4]), score, size, offset);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }

@@ -90,7 +90,7 @@ struct vt_model {
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
-    int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1;
+    int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1, chain_cus = 0;
     // Kernel form per stage: 1 / 0 force it, -1 (default) = by batch size.  The one-workgroup-per-frame forms win once the batch
     // fills the chip; below that the multi-workgroup forms spread a frame over several CUs (measured, us per step, tools/
     // small_batch_sweep.py: G128 B=1 97.6 -> 81.1, B=64 100.4 -> 86.1; G256 B=1 337 -> 287; crossovers at the thresholds below).
@@ -515,15 +515,16 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
 }
 
 // ViT-Base: towers + conv5 in vitb.hip, then the same decode kernel (first-index argmax, raw and Hann-windowed)
-int run_head_vitb(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o) {
-    float* score = (o && o->score_map) ? o->score_map : m->score.p;
-    float* size = (o && o->size_map) ? o->size_map : m->size.p;
-    float* offset = (o && o->offset_map) ? o->offset_map : m->offset.p;
-    float* pred = (o && o->pred_boxes) ? o->pred_boxes : m->pred.p;
-    float* hann = (o && o->hann_boxes) ? o->hann_boxes : m->hann.p;
-    float* conf = (o && o->conf) ? o->conf : m->conf.p;
+int run_head_vitb(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o, const vb::Slice* sl = nullptr) {
+    const size_t f0 = sl ? sl->f0 : 0, n = (size_t)m->len_x;       // outputs of the slice starting at frame f0
+    float* score = ((o && o->score_map) ? o->score_map : m->score.p) + f0 * n;
+    float* size = ((o && o->size_map) ? o->size_map : m->size.p) + f0 * 2 * n;
+    float* offset = ((o && o->offset_map) ? o->offset_map : m->offset.p) + f0 * 2 * n;
+    float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
+    float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
+    float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
     std::string err;
-    int rc = vb::head(m->vb, feat, B, st, score, size, offset, &err);
+    int rc = vb::head(m->vb, feat, B, st, score, size, offset, &err, sl);
     if (rc) return fail(rc, err);
     return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
 }
@@ -590,6 +591,14 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
     A(m->pred, B * 4); A(m->hann, B * 4); A(m->conf, B);
     if (!rc) rc = upload(m->window, hann2d(m->F));
     if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
+    // graph chains (vt_graph_capture_steps): frame slices of one step as concurrent chains, each on its share of the CUs
+    m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
+    m->chain_cus = env_int("VT_CHAIN_CUS", 0);
+    for (int i = 0; i < 3 && !rc; ++i)
+        if (hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->join_ev[i], hipEventDisableTiming) != hipSuccess)
+            rc = fail(VT_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+    if (!rc && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) rc = fail(VT_ERR_HIP, "hipEventCreate failed");
     if (rc) { vt_destroy(m); return rc; }
     *out = m;
     return VT_OK;
@@ -1040,8 +1049,18 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
 
 // One slice [f0, f0 + nb) of a batch through the whole step, on stream st.
 static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0, int nb, hipStream_t st,
-                         const vt_outputs* out) {
+                         const vt_outputs* out, int Btot, int nch) {
     const size_t Tz = m->cfg.template_size, Tx = m->cfg.search_size;
+    if (m->vb) {   // ViT-Base: the chains' persistent GEMMs split the CUs between them
+        int ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+        const vb::Slice sl{f0, Btot, m->chain_cus > 0 ? m->chain_cus : ncu / nch};
+        std::string err;
+        int rc;
+        if ((rc = vb::stem(m->vb, z + f0 * 3 * Tz * Tz, x + f0 * 3 * Tx * Tx, nb, st, nullptr, &err, &sl))) return fail(rc, err);
+        if ((rc = vb::blocks(m->vb, nullptr, nb, -1, st, nullptr, nullptr, &err, &sl))) return fail(rc, err);
+        return run_head_vitb(m, nullptr, nb, st, out, &sl);
+    }
     float* tok = m->tokens.p + f0 * m->L * 48;
     float* feat = m->feat.p + f0 * m->len_x * 48;
     int rc;
@@ -1060,7 +1079,7 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
     // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
     // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
     int nch = m->graph_chains;   // default 1
-    nch = (m->vb || nsteps > 1 || !z_dev || !z_dev[0]) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
+    nch = (nsteps > 1 || !z_dev || !z_dev[0]) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
@@ -1074,7 +1093,7 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
             if (hipStreamWaitEvent(m->side_stream[c - 1], m->fork_ev, 0) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamWaitEvent(fork)");
         for (int c = 0; c < nch && !rc; ++c) {
             const size_t f0 = (size_t)B * c / nch, f1 = (size_t)B * (c + 1) / nch;
-            rc = forward_slice(m, z_dev[0], x_dev[0], f0, (int)(f1 - f0), c == 0 ? m->cap_stream : m->side_stream[c - 1], out);
+            rc = forward_slice(m, z_dev[0], x_dev[0], f0, (int)(f1 - f0), c == 0 ? m->cap_stream : m->side_stream[c - 1], out, B, nch);
         }
         for (int c = 1; c < nch; ++c) {   // always join, even after an error, so the capture can end
             (void)hipEventRecord(m->join_ev[c - 1], m->side_stream[c - 1]);
