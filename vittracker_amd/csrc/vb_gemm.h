@@ -36,6 +36,21 @@
 #ifndef VB_GEMM_LINE2
 #define VB_GEMM_LINE2 1
 #endif
+#ifndef VB_SWP_NO_MFMA
+#define VB_SWP_NO_MFMA 0     // timing experiments only: the software-pipelined k-loop without its MFMAs (wrong results)
+#endif
+#ifndef VB_SWP_NO_DMA
+#define VB_SWP_NO_DMA 0      // timing experiments only: no operand staging inside the k-loop (wrong results)
+#endif
+#ifndef VB_SWP_NO_BARRIER
+#define VB_SWP_NO_BARRIER 0  // timing experiments only: no rendezvous per k-tile (races by design)
+#endif
+#ifndef VB_SWP_SPLIT
+#define VB_SWP_SPLIT 0       // 1: a k-tile's 8 DMA instructions per wave go out 4 + 4 in S7 / S8 instead of all behind the barrier
+#endif
+#ifndef VB_GEMM_SWP
+#define VB_GEMM_SWP 1        // wide tile: the software-pipelined k-loop with ONE barrier per k-tile (below); 0 = the phase-interleaved one
+#endif
 #ifndef VB_GEMM_PH8
 #define VB_GEMM_PH8 1        // wide tile: the phase-interleaved schedule with two staggered wave groups (below) instead of one burst per k-tile
 #endif
@@ -119,9 +134,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     //   LINE2: two stages of one 64-deep k-tile; a DMA piece is 8 rows x 128 B, i.e. WHOLE cache lines (half the L2 requests
     //          per byte of the 16-row x 64-byte pieces), XOR-swizzled by row (chunk ^ row): conflict-free ds_read_b128.
     //   PIPE4: four stages of one 32-deep k-step in 16-row x 64-byte pieces (st_16x32), counted vmcnt.
-    constexpr bool PH8 = WIDE && VB_GEMM_PH8;
-    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2 && !PH8;
-    constexpr bool PIPE4 = WIDE && !LINE2 && !PH8;
+    constexpr bool SWP = WIDE && VB_GEMM_SWP;
+    constexpr bool PH8 = WIDE && VB_GEMM_PH8 && !SWP;
+    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2 && !PH8 && !SWP;
+    constexpr bool PIPE4 = WIDE && !LINE2 && !PH8 && !SWP;
     constexpr int EP_OFF = 2 * BUF_BYTES;                                           // epilogue staging: 8 waves x 4 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -353,7 +369,234 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     tile_of(vb, m0, n0);
     load_bias(n0, bias_cur);
 
-    if constexpr (PH8) {
+    if constexpr (SWP) {
+        // ---- Software-pipelined k-loop, TWO barriers per k-tile, one DMA instruction per stage.  LDS as in the phase-interleaved
+        // form: two stages of one 64-deep k-tile (64 KiB each: X region 32 KiB | W region 32 KiB), pieces of 8 rows x 128 B (whole
+        // cache lines), chunk ^ row swizzle.  A wave's 64 MFMAs of a k-tile run as EIGHT stages of 8 (one accumulator quadrant x
+        // one 32-deep k-step) in snake order over the two k-steps
+        //     k0: Q00 Q01 Q11 Q10   k1: Q10 Q11 Q01 Q00        (Qxw = token half x, feature half w of the wave's 128 x 64)
+        // so consecutive stages share an operand, and each stage's MFMAs cover the fragment reads of LATER stages (X: two buffers
+        // XA / XB of 4 token tiles; W: all four (half, k-step) sets, so the W region is done with after S2) and ONE DMA instruction:
+        //     stage  MFMAs        fragment reads                         DMA (k-tile t is the current one)
+        //     S1  Q00 XA  W00     W10, XB <- X1[k0]                      X(t+1) piece 1
+        //     S2  Q01 XA  W10     W01, W11                               X(t+1) piece 2
+        //     S3  Q11 XB  W10     XA <- X1[k1]                           X(t+1) piece 3      B2: lgkmcnt(0), barrier -> W region of stage t free
+        //     S4  Q10 XB  W00                                            W(t+2) piece 0
+        //     S5  Q10 XA  W01     XB <- X0[k1]                           W(t+2) piece 1
+        //     S6  Q11 XA  W11                                            W(t+2) piece 2      B1: vmcnt(3) lgkmcnt(0), barrier -> stage t + 1 readable,
+        //     S7  Q01 XB  W11     XA <- X0[k0] of t + 1                  W(t+2) piece 3          X region of stage t free
+        //     S8  Q00 XB  W01     W00 <- W0[k0] of t + 1                 X(t+2) piece 0
+        // Why this shape (measured, tools/gpu_vbvar.sh): a DMA instruction is accepted only while the CU's vector-memory queue has
+        // room (the fill path moves 1 KiB per ~31-45 clk), so a wave that issues its 8 pieces back to back sits in front of its own
+        // MFMAs for most of the fill time -- with all 8 behind one barrier the k-loop took the SUM of its MFMA-only (0.99 us) and
+        // DMA-only (1.13 us) forms; paced at one piece per stage (8 waves x 1 per ~256 clk = the queue's rate) nothing queues.  The
+        // lead comes from releasing the W region early (B2) and the X region at B1: W runs a k-tile and a half ahead, X half a
+        // k-tile.  vmcnt(3) at B1 leaves W(t+2)'s three pieces in flight across the barrier.  The two waves of a SIMD drift
+        // apart between barriers, so one's LDS waits and DMA issue sit under the other's MFMAs.  Across tiles: the last k-tile's
+        // S7 / S8 stage the next tile's X(0), W(0), W(1) and X(1) piece 0 (both stages are free behind its B1), in front of the epilogue.
+        constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
+        constexpr int NQ = (PX + PW) / NWAVES;
+        static_assert(2 * STAGE_BYTES == EP_OFF && NQ == 8 && TM == 8 && TN == 4, "256 x 256 tile, 2 x 4 waves");
+        const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;
+        unsigned soff[NQ];                          // per-lane BYTE offsets of this wave's 8 DMA sources at k-tile 0
+        auto set_sources_s = [&](int m0, int n0) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int p = w + NWAVES * i;
+                if (i < NQ / 2) {
+                    int m = m0 + p * 8 + drow;
+                    m = m < a.M ? m : a.M - 1;
+                    unsigned base;
+                    if constexpr (AMODE == A_CONV) {
+                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
+                        base = (unsigned)(((b * P + y) * P + x) * a.C);
+                    } else {
+                        base = (unsigned)m * (unsigned)a.K;
+                    }
+                    soff[i] = (base + dk) * 2u;
+                } else {
+                    soff[i] = ((unsigned)(n0 + (p - PX) * 8 + drow) * (unsigned)a.K + dk) * 2u;
+                }
+            }
+        };
+        auto kx_of = [&](int kt) -> unsigned {      // element offset of k-tile kt along an X row
+            if constexpr (AMODE == A_CONV) {
+                const int per_tap = a.C / BK, tap = kt / per_tap, c0 = (kt - tap * per_tap) * BK, r = tap / 3, sx = tap - 3 * r;
+                return (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
+            } else {
+                return (unsigned)kt * BK;
+            }
+        };
+        auto issue1 = [&](int stg, int kt, unsigned kx, int i) {      // DMA instruction i (0-3: X pieces, 4-7: W pieces) of k-tile kt -> stage stg
+#if VB_SWP_NO_DMA
+            return;
+#endif
+            // wave-uniform 64-bit base (pinned into an SGPR pair) + 32-bit per-lane byte offset: the saddr form of the instruction,
+            // one VGPR per source and no address arithmetic on the VALU; the LDS destination is wave-uniform too (M0; the hardware
+            // adds lane x 16)
+            const unsigned long long b64 = i < NQ / 2 ? reinterpret_cast<unsigned long long>(X) + (unsigned long long)kx * 2
+                                                      : reinterpret_cast<unsigned long long>(W) + (unsigned long long)((unsigned)kt * BK) * 2;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+            const char* base = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+            unsigned off = soff[i];
+            asm volatile("" : "+v"(off));        // opaque: otherwise LICM hoists base + offset as 64-bit per-lane pointers (16 registers) out of the k-loop
+            glds16(base + (size_t)off, smem + stg * STAGE_BYTES + (w + NWAVES * i) * 1024);
+        };
+        const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
+        const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
+        const int nk = a.K / BK;                    // even (checked by the host)
+        bf16x8 XA[4], XB[4], W00[2], W10[2], W01[2], W11[2];     // W<half><k-step>
+        // fragment addresses: one opaque base register per (operand, k-step, stage) + an immediate below 16 KiB.  Opaque, because
+        // stage 1 lies beyond the 16-bit offset field and hipcc otherwise materialises one address register PER READ (~30)
+        int fxa[2][2], fwa[2][2];                    // [stage][k-step]
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                fxa[st][kk] = (wm * TM * 2) * 1024 + (kk ? fk1 : fk0) + st * STAGE_BYTES;
+                fwa[st][kk] = (PX + wn * TN * 2) * 1024 + (kk ? fk1 : fk0) + st * STAGE_BYTES;
+                asm volatile("" : "+v"(fxa[st][kk]), "+v"(fwa[st][kk]));
+            }
+        auto ldx = [&](bf16x8 (&fx)[4], auto stg, int half, int kk) {
+            const char* xp = smem + fxa[decltype(stg)::value][kk] + half * 8 * 1024;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + j * 2048);
+        };
+        auto ldw = [&](bf16x8 (&fw)[2], auto stg, int half, int kk) {
+            const char* wp = smem + fwa[decltype(stg)::value][kk] + half * 4 * 1024;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + i * 2048);
+        };
+        auto mma8 = [&](int xh, int wh, const bf16x8 (&fx)[4], const bf16x8 (&fw)[2]) {
+#if !VB_SWP_NO_MFMA
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (EPI == EPI_VT)
+                        acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
+                    else
+                        acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
+                }
+#endif
+        };
+        auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+        auto bar = [&]() {
+#if !VB_SWP_NO_BARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+        };
+        bool more = true;
+        int cm0 = m0, cn0 = n0;
+        const std::integral_constant<int, 0> S0{};
+        const std::integral_constant<int, 1> S1{};
+        // One k-tile in stage STG -- straight-line code, no branch inside (a branch would put the MFMAs and the loads they are
+        // meant to cover into different scheduling regions).  K is a multiple of 128, so a tile starts in stage 0 and ends in
+        // stage 1; the last two k-tiles of a tile are their own instantiations: FILL1 = k-tile kt + 1 exists (X pieces 1-3 in
+        // S1-S3), FILL2 = k-tile kt + 2 exists (W pieces in S4-S7, X piece 0 in S8), LAST = the tile's last k-tile.
+        auto ktile = [&](int kt, auto stg, auto fill1, auto fill2, auto last_) {
+            constexpr int STG = decltype(stg)::value;
+            constexpr bool FILL1 = decltype(fill1)::value, FILL2 = decltype(fill2)::value, LAST = decltype(last_)::value;
+            const std::integral_constant<int, STG ^ 1> nstg{};
+            const unsigned kx1 = FILL1 ? kx_of(kt + 1) : 0u, kx2 = FILL2 ? kx_of(kt + 2) : 0u;
+            // S1
+            mma8(0, 0, XA, W00);
+            ldw(W10, stg, 1, 0);
+            ldx(XB, stg, 1, 0);
+            if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 1);
+            SB();
+            // S2
+            mma8(0, 1, XA, W10);
+            ldw(W01, stg, 0, 1);
+            ldw(W11, stg, 1, 1);
+            if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 2);
+            SB();
+            // S3
+            mma8(1, 1, XB, W10);
+            ldx(XA, stg, 1, 1);
+            if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 3);
+            SB();
+            // B2: every W fragment of this k-tile is in registers -> the W region of this stage may be re-staged
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+            SB();
+            // S4
+            mma8(1, 0, XB, W00);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 4);
+            SB();
+            // S5
+            mma8(1, 0, XA, W01);
+            ldx(XB, stg, 0, 1);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 5);
+            SB();
+            // S6
+            mma8(1, 1, XA, W11);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 6);
+            SB();
+            // B1: k-tile kt + 1 has landed (all but the three W pieces just issued), this stage's X fragments are all in registers
+            if constexpr (FILL2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            bar();
+            SB();
+            if constexpr (!LAST) {
+                // S7
+                mma8(0, 1, XB, W11);
+                ldx(XA, nstg, 0, 0);
+                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 7);
+                SB();
+                // S8
+                mma8(0, 0, XB, W01);
+                ldw(W00, nstg, 0, 0);
+                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 0);
+                SB();
+            } else {
+                // both stages are free: the next tile's X(0), W(0), W(1) and X(1) piece 0 go out under the last 16 MFMAs
+                vb += gridDim.x;
+                more = vb < nwg;
+                mma8(0, 1, XB, W11);
+                if (more) {
+                    tile_of(vb, m0, n0);
+                    set_sources_s((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) issue1(0, 0, kx_of(0), i);
+                }
+                SB();
+                mma8(0, 0, XB, W01);
+                if (more) {
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) issue1(1, 1, kx_of(1), i);
+                    issue1(1, 1, kx_of(1), 0);
+                }
+                SB();
+            }
+        };
+        set_sources_s((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue1(0, 0, kx_of(0), i);
+#pragma unroll
+        for (int i = 4; i < 8; ++i) issue1(1, 1, kx_of(1), i);
+        issue1(1, 1, kx_of(1), 0);
+        const std::true_type T{};
+        const std::false_type Fa{};
+        for (;;) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ldx(XA, S0, 0, 0);
+            ldw(W00, S0, 0, 0);
+            zero_acc();
+            cm0 = m0; cn0 = n0;
+            for (int kt = 0; kt + 2 < nk; kt += 2) {
+                ktile(kt, S0, T, T, Fa);
+                ktile(kt + 1, S1, T, T, Fa);
+            }
+            ktile(nk - 2, S0, T, Fa, Fa);
+            ktile(nk - 1, S1, Fa, Fa, T);
+            if (more) load_bias(n0, bias_nxt);
+            if (!(a.dbg & 8)) epilogue(cm0, cn0);
+            if (!more) break;
+            roll_bias();
+        }
+    } else if constexpr (PH8) {
         // ---- Phase-interleaved schedule (cdna_hip_programming.md "The 256^2 8-phase template", rebuilt for this tile).
         // Two LDS stages of one 64-deep k-tile (64 KiB each) in whole-line pieces as LINE2; a k-tile is FOUR half-panels of
         // 16 KiB: X rows 0-127 | X rows 128-255 | W rows 0-127 | W rows 128-255, each staged by all 8 waves with 2 DMA

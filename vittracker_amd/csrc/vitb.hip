@@ -112,6 +112,7 @@ int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E, in
     if (a.M < 1 || a.K % vbg::BK != 0 || a.N % 8 != 0)
         return E.fail(VT_ERR_ARG, "gemm shape: K must be a multiple of 64 and N of 8 (got M=" + std::to_string(a.M) + " N=" +
                                       std::to_string(a.N) + " K=" + std::to_string(a.K) + ")");
+    if (BM == 256 && BN == 256 && a.K % (2 * vbg::BK) != 0) return E.fail(VT_ERR_ARG, "gemm shape: the 256 x 256 tile needs K to be a multiple of 128");
     static const int dbg = [] { const char* v = std::getenv("VB_DBG"); return v ? std::atoi(v) : 0; }();
     vbg::Args ad = a;
     ad.dbg = dbg;
