@@ -45,6 +45,12 @@
 #ifndef VB_SWP_NO_BARRIER
 #define VB_SWP_NO_BARRIER 0  // timing experiments only: no rendezvous per k-tile (races by design)
 #endif
+#ifndef VB_EPI_NT
+#define VB_EPI_NT 0          // 1: every epilogue's stores (and the residual's loads) carry the non-temporal hint (measured: +-0 except
+#endif                       //    the transposed V stores, which always carry it: v projection 100 -> 92 us)
+#ifndef VB_SWP_HALFISSUE
+#define VB_SWP_HALFISSUE 0   // 1: only the wm = 0 waves issue the DMA instructions (two per slot)
+#endif
 #ifndef VB_SWP_SPLIT
 #define VB_SWP_SPLIT 0       // 1: a k-tile's 8 DMA instructions per wave go out 4 + 4 in S7 / S8 instead of all behind the barrier
 #endif
@@ -62,6 +68,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;
 constexpr int NWAVES = 8;
@@ -95,6 +102,8 @@ struct Args {
     int n_split;          // EPI_CONV with towers concatenated along N: columns per tower (0 = none); tower t writes out + t * gOut
     int rb;               // tile order: > 1 = tiles are walked in blocks of `rb` tile rows, column by column inside a block (so the
                           // 32 concurrent tiles of an XCD are ~rb rows x 32 / rb columns); 0 / 1 = row-major
+    int desync_ticks;     // > 0: workgroup phase groups -- group g = (blockIdx.x / 8) % desync_groups starts g * desync_ticks / desync_groups
+    int desync_groups;    // ticks of the 100 MHz clock late, so the CUs' epilogues (HBM) and k-loops (MFMA) do not all coincide
     int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
                           // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
                           // 4 = no MFMAs, 8 = no epilogue, 16 = no W staging, 32 = no X staging (wide tile)
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                     const int m = mw + ch * 8, n = nw + i * 16 + row;
                     if (!CHECK || m < a.M) {      // M is a multiple of 8 (L is): 8 tokens never straddle a frame or the end
                         const int f = m / a.L, tk = m - f * a.L;
-                        *reinterpret_cast<uint4*>(a.vt + ((size_t)f * a.N + n) * a.L + tk) = v;
+                        __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(a.vt + ((size_t)f * a.N + n) * a.L + tk));
                     }
                 }
                 lds_fence();
@@ -276,7 +285,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 for (int t = 0; t < 4; ++t) {
                     const int m = mw + j * 16 + 4 * t + r0;
                     const int mc = CHECK ? (m < a.M ? m : a.M - 1) : m;
-                    if constexpr (EPI == EPI_RESID) old[t] = ld4(a.resid + (size_t)mc * a.N + nw + ch * 4);
+                    if constexpr (EPI == EPI_RESID)
+                        old[t] = VB_EPI_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.resid + (size_t)mc * a.N + nw + ch * 4))
+                                           : ld4(a.resid + (size_t)mc * a.N + nw + ch * 4);
                     else old[t] = ld4(a.pos + (size_t)(mc % a.L) * a.N + nw + ch * 4);
                 }
                 lds_fence();
@@ -284,7 +295,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 for (int t = 0; t < 4; ++t) {
                     const int row = 4 * t + r0, m = mw + j * 16 + row;
                     const f4 v = *reinterpret_cast<const f4a*>(ep + row * 256 + ((ch ^ row) << 4));
-                    if (!CHECK || m < a.M) st4(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
+                    if (!CHECK || m < a.M) {
+                        if (VB_EPI_NT) st4_nt(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
+                        else st4(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
+                    }
                 }
                 lds_fence();
             }
@@ -325,7 +339,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                         orow = (size_t)((bb * P + y + 1) * P + x + 1);
                     }
                 }
-                *reinterpret_cast<uint4*>(obase + orow * a.ldo + ncol + ch * 8) = v;
+                if (VB_EPI_NT) __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(&v), reinterpret_cast<u32x4*>(obase + orow * a.ldo + ncol + ch * 8));
+                else *reinterpret_cast<uint4*>(obase + orow * a.ldo + ncol + ch * 8) = v;
             }
             lds_fence();
         }
@@ -376,34 +391,39 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
         // one 32-deep k-step) in snake order over the two k-steps
         //     k0: Q00 Q01 Q11 Q10   k1: Q10 Q11 Q01 Q00        (Qxw = token half x, feature half w of the wave's 128 x 64)
         // so consecutive stages share an operand, and each stage's MFMAs cover the fragment reads of LATER stages (X: two buffers
-        // XA / XB of 4 token tiles; W: all four (half, k-step) sets, so the W region is done with after S2) and ONE DMA instruction:
+        // XA / XB of 4 token tiles; W: all four (half, k-step) sets, so the W region is done with after S1) and ONE DMA instruction:
         //     stage  MFMAs        fragment reads                         DMA (k-tile t is the current one)
-        //     S1  Q00 XA  W00     W10, XB <- X1[k0]                      X(t+1) piece 1
-        //     S2  Q01 XA  W10     W01, W11                               X(t+1) piece 2
-        //     S3  Q11 XB  W10     XA <- X1[k1]                           X(t+1) piece 3      B2: lgkmcnt(0), barrier -> W region of stage t free
-        //     S4  Q10 XB  W00                                            W(t+2) piece 0
-        //     S5  Q10 XA  W01     XB <- X0[k1]                           W(t+2) piece 1
-        //     S6  Q11 XA  W11                                            W(t+2) piece 2      B1: vmcnt(3) lgkmcnt(0), barrier -> stage t + 1 readable,
-        //     S7  Q01 XB  W11     XA <- X0[k0] of t + 1                  W(t+2) piece 3          X region of stage t free
-        //     S8  Q00 XB  W01     W00 <- W0[k0] of t + 1                 X(t+2) piece 0
+        //     S1  Q00 XA  W00     W10, W01, W11                          X(t+1) piece 2
+        //     S2  Q01 XA  W10     XB <- X1[k0]                           X(t+1) piece 3      B2: lgkmcnt(0), barrier -> W region of stage t free
+        //     S3  Q11 XB  W10     XA <- X1[k1]                           W(t+2) piece 0
+        //     S4  Q10 XB  W00                                            W(t+2) piece 1
+        //     S5  Q10 XA  W01     XB <- X0[k1]                           W(t+2) piece 2
+        //     S6  Q11 XA  W11                                            W(t+2) piece 3      B1: vmcnt(4) lgkmcnt(0), barrier -> stage t + 1 readable,
+        //     S7  Q01 XB  W11     XA <- X0[k0] of t + 1                  X(t+2) piece 0          X region of stage t free
+        //     S8  Q00 XB  W01     W00 <- W0[k0] of t + 1                 X(t+2) piece 1
         // Why this shape (measured, tools/gpu_vbvar.sh): a DMA instruction is accepted only while the CU's vector-memory queue has
         // room (the fill path moves 1 KiB per ~31-45 clk), so a wave that issues its 8 pieces back to back sits in front of its own
         // MFMAs for most of the fill time -- with all 8 behind one barrier the k-loop took the SUM of its MFMA-only (0.99 us) and
         // DMA-only (1.13 us) forms; paced at one piece per stage (8 waves x 1 per ~256 clk = the queue's rate) nothing queues.  The
         // lead comes from releasing the W region early (B2) and the X region at B1: W runs a k-tile and a half ahead, X half a
-        // k-tile.  vmcnt(3) at B1 leaves W(t+2)'s three pieces in flight across the barrier.  The two waves of a SIMD drift
+        // k-tile.  vmcnt(4) at B1 leaves W(t+2)'s four pieces in flight across the barrier.  The two waves of a SIMD drift
         // apart between barriers, so one's LDS waits and DMA issue sit under the other's MFMAs.  Across tiles: the last k-tile's
-        // S7 / S8 stage the next tile's X(0), W(0), W(1) and X(1) piece 0 (both stages are free behind its B1), in front of the epilogue.
+        // S7 / S8 stage the next tile's X(0), W(0), W(1) and X(1) pieces 0, 1 (both stages are free behind its B1), in front of the epilogue.
         constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
         constexpr int NQ = (PX + PW) / NWAVES;
         static_assert(2 * STAGE_BYTES == EP_OFF && NQ == 8 && TM == 8 && TN == 4, "256 x 256 tile, 2 x 4 waves");
         const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;
-        unsigned soff[NQ];                          // per-lane BYTE offsets of this wave's 8 DMA sources at k-tile 0
+        // VB_SWP_HALFISSUE: only the wm = 0 waves (one per SIMD) issue DMA instructions, two per slot (16 per k-tile); their SIMD
+        // partners (wm = 1) issue none and keep the matrix pipe busy meanwhile.
+        constexpr bool HALF = VB_SWP_HALFISSUE != 0;
+        constexpr int NSRC = HALF ? 2 * NQ : NQ;
+        auto piece_of = [&](int j) { return HALF ? wn + (NWAVES / 2) * j : w + NWAVES * j; };     // j-th piece of this wave: 0 .. PX-1 X, then W
+        unsigned soff[NSRC];                        // per-lane BYTE offsets of this wave's DMA sources at k-tile 0
         auto set_sources_s = [&](int m0, int n0) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int p = w + NWAVES * i;
-                if (i < NQ / 2) {
+            for (int i = 0; i < NSRC; ++i) {
+                const int p = piece_of(i);
+                if (i < NSRC / 2) {
                     int m = m0 + p * 8 + drow;
                     m = m < a.M ? m : a.M - 1;
                     unsigned base;
@@ -427,10 +447,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 return (unsigned)kt * BK;
             }
         };
-        auto issue1 = [&](int stg, int kt, unsigned kx, int i) {      // DMA instruction i (0-3: X pieces, 4-7: W pieces) of k-tile kt -> stage stg
+        auto issue1 = [&](int stg, int kt, unsigned kx, int i) {      // DMA slot i (0-3: X pieces, 4-7: W pieces) of k-tile kt -> stage stg
 #if VB_SWP_NO_DMA
             return;
 #endif
+            if (HALF && wm != 0) return;
             // wave-uniform 64-bit base (pinned into an SGPR pair) + 32-bit per-lane byte offset: the saddr form of the instruction,
             // one VGPR per source and no address arithmetic on the VALU; the LDS destination is wave-uniform too (M0; the hardware
             // adds lane x 16)
@@ -438,9 +459,13 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                                                       : reinterpret_cast<unsigned long long>(W) + (unsigned long long)((unsigned)kt * BK) * 2;
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
             const char* base = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-            unsigned off = soff[i];
-            asm volatile("" : "+v"(off));        // opaque: otherwise LICM hoists base + offset as 64-bit per-lane pointers (16 registers) out of the k-loop
-            glds16(base + (size_t)off, smem + stg * STAGE_BYTES + (w + NWAVES * i) * 1024);
+#pragma unroll
+            for (int jj = 0; jj < (HALF ? 2 : 1); ++jj) {
+                const int j = HALF ? 2 * i + jj : i;
+                unsigned off = soff[j];
+                asm volatile("" : "+v"(off));    // opaque: otherwise LICM hoists base + offset as 64-bit per-lane pointers (16 registers) out of the k-loop
+                glds16(base + (size_t)off, smem + stg * STAGE_BYTES + piece_of(j) * 1024);
+            }
         };
         const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
         const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
@@ -492,8 +517,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
         const std::integral_constant<int, 1> S1{};
         // One k-tile in stage STG -- straight-line code, no branch inside (a branch would put the MFMAs and the loads they are
         // meant to cover into different scheduling regions).  K is a multiple of 128, so a tile starts in stage 0 and ends in
-        // stage 1; the last two k-tiles of a tile are their own instantiations: FILL1 = k-tile kt + 1 exists (X pieces 1-3 in
-        // S1-S3), FILL2 = k-tile kt + 2 exists (W pieces in S4-S7, X piece 0 in S8), LAST = the tile's last k-tile.
+        // stage 1; the last two k-tiles of a tile are their own instantiations: FILL1 = k-tile kt + 1 exists (X pieces 2, 3 in
+        // S1, S2), FILL2 = k-tile kt + 2 exists (W pieces in S3-S6, X pieces 0, 1 in S7, S8), LAST = the tile's last k-tile.
         auto ktile = [&](int kt, auto stg, auto fill1, auto fill2, auto last_) {
             constexpr int STG = decltype(stg)::value;
             constexpr bool FILL1 = decltype(fill1)::value, FILL2 = decltype(fill2)::value, LAST = decltype(last_)::value;
@@ -502,39 +527,40 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             // S1
             mma8(0, 0, XA, W00);
             ldw(W10, stg, 1, 0);
-            ldx(XB, stg, 1, 0);
-            if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 1);
-            SB();
-            // S2
-            mma8(0, 1, XA, W10);
             ldw(W01, stg, 0, 1);
             ldw(W11, stg, 1, 1);
             if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 2);
             SB();
-            // S3
-            mma8(1, 1, XB, W10);
-            ldx(XA, stg, 1, 1);
+            // S2
+            mma8(0, 1, XA, W10);
+            ldx(XB, stg, 1, 0);
             if constexpr (FILL1) issue1(STG ^ 1, kt + 1, kx1, 3);
             SB();
-            // B2: every W fragment of this k-tile is in registers -> the W region of this stage may be re-staged
+            // B2: every W fragment of this k-tile is in registers (read in S1) -> the W region of this stage may be re-staged
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bar();
             SB();
+            // S3
+            mma8(1, 1, XB, W10);
+            ldx(XA, stg, 1, 1);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 4);
+            SB();
             // S4
             mma8(1, 0, XB, W00);
-            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 4);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 5);
             SB();
             // S5
             mma8(1, 0, XA, W01);
             ldx(XB, stg, 0, 1);
-            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 5);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 6);
             SB();
             // S6
             mma8(1, 1, XA, W11);
-            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 6);
+            if constexpr (FILL2) issue1(STG, kt + 2, kx2, 7);
             SB();
-            // B1: k-tile kt + 1 has landed (all but the three W pieces just issued), this stage's X fragments are all in registers
-            if constexpr (FILL2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            // B1: k-tile kt + 1 has landed (all but the four W pieces just issued), this stage's X fragments are all in registers
+            if constexpr (FILL2 && HALF) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");      // (wm = 1 waves have nothing outstanding)
+            else if constexpr (FILL2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             bar();
             SB();
@@ -542,15 +568,15 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 // S7
                 mma8(0, 1, XB, W11);
                 ldx(XA, nstg, 0, 0);
-                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 7);
+                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 0);
                 SB();
                 // S8
                 mma8(0, 0, XB, W01);
                 ldw(W00, nstg, 0, 0);
-                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 0);
+                if constexpr (FILL2) issue1(STG, kt + 2, kx2, 1);
                 SB();
             } else {
-                // both stages are free: the next tile's X(0), W(0), W(1) and X(1) piece 0 go out under the last 16 MFMAs
+                // both stages are free: the next tile's X(0), W(0), W(1) and X(1) pieces 0, 1 go out under the last 16 MFMAs
                 vb += gridDim.x;
                 more = vb < nwg;
                 mma8(0, 1, XB, W11);
@@ -566,16 +592,23 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
 #pragma unroll
                     for (int i = 4; i < 8; ++i) issue1(1, 1, kx_of(1), i);
                     issue1(1, 1, kx_of(1), 0);
+                    issue1(1, 1, kx_of(1), 1);
                 }
                 SB();
             }
         };
+        if (a.desync_ticks > 0) {       // phase offset of this workgroup (all its tiles take the same time, so the offset persists)
+            const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) % a.desync_groups) * a.desync_ticks / a.desync_groups;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
         set_sources_s((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) issue1(0, 0, kx_of(0), i);
 #pragma unroll
         for (int i = 4; i < 8; ++i) issue1(1, 1, kx_of(1), i);
         issue1(1, 1, kx_of(1), 0);
+        issue1(1, 1, kx_of(1), 1);
         const std::true_type T{};
         const std::false_type Fa{};
         for (;;) {

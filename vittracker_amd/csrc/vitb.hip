@@ -121,6 +121,17 @@ int launch_gemm(const vbg::Args& a, int groups, hipStream_t st, const Err& E, in
                                    env_int("VB_RB_4", -1), env_int("VB_RB_5", -1)};
         if (rbs[EPI] >= 0) ad.rb = rbs[EPI];
     }
+    {   // experiment hook: VB_DESYNC_<epilogue id>=<us>[:groups] -- phase groups of workgroups (Args::desync_ticks)
+        static const struct D { int us[6], g[6]; D() {
+            for (int e = 0; e < 6; ++e) {
+                const std::string n = "VB_DESYNC_" + std::to_string(e);
+                const char* v = std::getenv(n.c_str());
+                us[e] = v ? std::atoi(v) : 0;
+                const char* c = v ? std::strchr(v, ':') : nullptr;
+                g[e] = c ? std::max(2, std::atoi(c + 1)) : 2;
+            } } } ds;
+        if (ds.us[EPI] > 0) { ad.desync_ticks = ds.us[EPI] * 100; ad.desync_groups = ds.g[EPI]; }
+    }
     // persistent workgroups: one per CU, each walks tiles blockIdx.x, blockIdx.x + grid, ...
     const int ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     static const int max_cus = env_int("VB_MAX_CUS", 0);      // experiment hook: persistent grid of at most this many workgroups
