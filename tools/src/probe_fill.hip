@@ -91,6 +91,43 @@ void run(const char* name, const char* X, const char* W, unsigned* sink, unsigne
     printf("%-58s wgs %3d: %7.1f us, %5.2f us per 64 KiB k-tile = %5.1f GB/s per CU, %5.1f clk per KiB\n", name, wgs, ms * 1e3, us_per_kt,
            65536.0 / us_per_kt / 1e3, cs / ktiles / 64.0);
 }
+// ---- store side: each workgroup writes "tiles" of 256 rows x 512 B (a 256 x 256 bf16 output tile, row pitch = pitch bytes), as the
+// GEMM epilogue does: one wave-instruction = 8 rows x 128 B (PATTERN 0) or 2 rows x 512 B (PATTERN 1); NT = non-temporal hint.
+template <int PATTERN, int NT>
+__global__ __launch_bounds__(512) void spill(char* __restrict__ out, int tiles_per_wg, int tiles_n, size_t pitch) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    u4 v = {(unsigned)tid, 1u, 2u, 3u};
+    for (int t = 0; t < tiles_per_wg; ++t) {
+        const int tile = blockIdx.x + t * gridDim.x, tn = tile % tiles_n, tm = tile / tiles_n;
+        char* base = out + (size_t)tm * 256 * pitch + (size_t)tn * 512;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {        // 16 wave-instructions per wave = 16 KiB; 8 waves = 128 KiB
+            char* p;
+            if (PATTERN == 0) {               // wave w owns column slice (w & 3) * 128 B of rows (w >> 2) * 128 + i * 8 + lane / 8
+                const int r = (w >> 2) * 128 + i * 8 + (lane >> 3);
+                p = base + (size_t)r * pitch + (w & 3) * 128 + (lane & 7) * 16;
+            } else {                          // wave w owns rows w * 32 + i * 2 + lane / 32, 512 B each
+                const int r = w * 32 + i * 2 + (lane >> 5);
+                p = base + (size_t)r * pitch + (lane & 31) * 16;
+            }
+            if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(p));
+            else *reinterpret_cast<u4*>(p) = v;
+            v.x += 1;
+        }
+    }
+}
+template <int PATTERN, int NT>
+void run_store(const char* name, char* out, int wgs) {
+    const int tiles_n = 6, tiles_m = 320, per = tiles_n * tiles_m / 256;       // qk: N = 1536 -> 6 column tiles, pitch 3072 B; 7 tiles per workgroup
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((spill<PATTERN, NT>), dim3(wgs), dim3(512), 0, 0, out, per, tiles_n, (size_t)3072);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((spill<PATTERN, NT>), dim3(wgs), dim3(512), 0, 0, out, per, tiles_n, (size_t)3072);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+    printf("%-58s wgs %3d: %7.1f us, %5.2f us per 128 KiB tile = %5.1f GB/s per CU, %5.2f TB/s\n", name, wgs, ms * 1e3, ms * 1e3 / per,
+           131072.0 / (ms * 1e3 / per) / 1e3, 131072.0 * per * wgs / (ms * 1e-3) / 1e12);
+}
 int main() {
     char *X, *W; unsigned* sink; unsigned long long* cyc;
     hipMalloc(&X, (size_t)M * KB); hipMalloc(&W, (size_t)N * KB); hipMalloc(&sink, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8);
@@ -102,5 +139,12 @@ int main() {
         run<2, 1>("C global_load_dwordx4 only, 1 k-tile in flight", X, W, sink, cyc, wgs);
     }
     run<0, 1>("A LDS-DMA, 1 k-tile in flight", X, W, sink, cyc, 256);
+    char* out; hipMalloc(&out, (size_t)320 * 256 * 3072);
+    for (int wgs : {256, 128, 64}) {
+        run_store<0, 0>("D stores, 8 rows x 128 B per instruction", out, wgs);
+        run_store<0, 1>("E the same, non-temporal", out, wgs);
+        run_store<1, 0>("F stores, 2 rows x 512 B per instruction", out, wgs);
+        run_store<1, 1>("G the same, non-temporal", out, wgs);
+    }
     return 0;
 }

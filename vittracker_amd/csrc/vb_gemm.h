@@ -55,7 +55,7 @@
 #define VB_SWP_SPLIT 0       // 1: a k-tile's 8 DMA instructions per wave go out 4 + 4 in S7 / S8 instead of all behind the barrier
 #endif
 #ifndef VB_GEMM_SWP
-#define VB_GEMM_SWP 1        // wide tile: the software-pipelined k-loop with ONE barrier per k-tile (below); 0 = the phase-interleaved one
+#define VB_GEMM_SWP 1        // wide tile: the software-pipelined k-loop, two barriers per k-tile (below); 0 = the phase-interleaved one
 #endif
 #ifndef VB_GEMM_PH8
 #define VB_GEMM_PH8 1        // wide tile: the phase-interleaved schedule with two staggered wave groups (below) instead of one burst per k-tile
