@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ViT-Base: the captured step as 1..4 concurrent chains over frame slices (VT_GRAPH_CHAINS, VT_CHAIN_CUS): ms per step in ONE box
+"""ViT-Base: the captured step as 1..4 concurrent chains over frame slices (VT_GRAPH_CHAINS, VT_CHAIN_CUS, VT_CHAIN_DELAY_US; a case is chains:cus[:delay_us]): ms per step in ONE box
 session, and chained graph == eager forward bit for bit.     python tools/vitb_chains.py [--B 256] [--cases 1:0,2:0,2:160,3:0,4:0]"""
 import argparse, json, os, statistics, subprocess, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -33,7 +33,7 @@ def main():
     res = {c: [] for c in cases}
     for _ in range(a.rounds):
         for c in cases:
-            env = dict(os.environ, VT_GRAPH_CHAINS=str(c[0]), VT_CHAIN_CUS=str(c[1]))
+            env = dict(os.environ, VT_GRAPH_CHAINS=str(c[0]), VT_CHAIN_CUS=str(c[1]), VT_CHAIN_DELAY_US=str(c[2] if len(c) > 2 else 0))
             p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "B": a.B, "steps": a.steps}], capture_output=True, text=True, timeout=900, env=env)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
             if p.returncode or not line:
@@ -41,7 +41,7 @@ def main():
             res[c].append(json.loads(line[0][7:]))
     for c, rows in res.items():
         if rows:
-            print(f"vitb chains {c[0]} cus/chain {c[1] or 'auto':>4}: ms/step median {statistics.median(r['ms'] for r in rows):.3f} min {min(r['ms'] for r in rows):.3f}  "
+            print(f"vitb chains {c[0]} cus/chain {c[1] or 'auto':>4} delay {c[2] if len(c) > 2 else 0:>4} us: ms/step median {statistics.median(r['ms'] for r in rows):.3f} min {min(r['ms'] for r in rows):.3f}  "
                   f"frames/s max {max(r['fps'] for r in rows):.0f}  graph == eager: {all(r['same_as_eager'] for r in rows)}")
 if __name__ == "__main__":
     main()

@@ -90,7 +90,7 @@ struct vt_model {
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     unsigned long long* dbg_stamps = nullptr;   // VT_DBG_STAMPS=1: per-wave phase stamps of the block kernel
     // diagnostic switches, read from the environment ONCE at vt_create (all 0 / -1 in production)
-    int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1, chain_cus = 0;
+    int skip_stem_a = 0, skip_stem_b = 0, skip_head = 0, dbg_skip_tile = -1, graph_chains = 1, chain_cus = 0, chain_delay_us = 0;
     // Kernel form per stage: 1 / 0 force it, -1 (default) = by batch size.  The one-workgroup-per-frame forms win once the batch
     // fills the chip; below that the multi-workgroup forms spread a frame over several CUs (measured, us per step, tools/
     // small_batch_sweep.py: G128 B=1 97.6 -> 81.1, B=64 100.4 -> 86.1; G256 B=1 337 -> 287; crossovers at the thresholds below).
@@ -529,6 +529,12 @@ int run_head_vitb(vt_model* m, const float* feat, int B, hipStream_t st, const v
     return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
 }
 
+// Graph chains: a chain may start late (VT_CHAIN_DELAY_US x chain index), so that identical chains do not run in lock step
+__global__ void chain_delay_kernel(unsigned long long ticks) {      // 100 MHz ticks
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // ------------------------------------------------------------------------------------ self test
 __global__ void mfma_selftest_kernel(const float* A, const float* Bm, float* D) {
     // A (16x16 k-chunk as operand image source: A[i][k]), B[k][j]; D[i][j] = sum_k A[i][k] B[k][j]
@@ -594,6 +600,7 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
     // graph chains (vt_graph_capture_steps): frame slices of one step as concurrent chains, each on its share of the CUs
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->chain_cus = env_int("VT_CHAIN_CUS", 0);
+    m->chain_delay_us = env_int("VT_CHAIN_DELAY_US", 0);
     for (int i = 0; i < 3 && !rc; ++i)
         if (hipStreamCreateWithFlags(&m->side_stream[i], hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&m->join_ev[i], hipEventDisableTiming) != hipSuccess)
@@ -1051,6 +1058,10 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
 static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0, int nb, hipStream_t st,
                          const vt_outputs* out, int Btot, int nch) {
     const size_t Tz = m->cfg.template_size, Tx = m->cfg.search_size;
+    if (m->chain_delay_us > 0 && f0 > 0) {
+        const int c = (int)((f0 * (size_t)nch + (size_t)Btot - 1) / (size_t)Btot);      // chain index of this slice
+        hipLaunchKernelGGL(chain_delay_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)c * m->chain_delay_us * 100ull);
+    }
     if (m->vb) {   // ViT-Base: the chains' persistent GEMMs split the CUs between them
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
