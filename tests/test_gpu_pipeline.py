@@ -141,6 +141,42 @@ def test_batched_tracker_equals_independent_plugin_trackers():
     np.testing.assert_array_equal(last["target_bbox"].cpu().numpy(), out["target_bbox"].numpy())
 
 
+def test_frames_read_in_place_from_pinned_memory_equal_uploaded_frames(monkeypatch):
+    """Small host frames are copied by the CPU into pinned slots that the crop kernel reads over the bus (no upload); larger ones are
+    uploaded into device slots.  Same kernels on the same pixels: boxes and confidences must be identical, with and without a
+    synchronisation per step (two slots, the writer of a slot waits for the step that last read it)."""
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.parameter import vit_dist as P
+    os.environ["VITTRACK_PRJ_DIR"] = REPO
+    p = P.parameters("vit_48_h32_g128")
+    p.allow_synthetic_weights = True
+    p.debug = 0
+    B, n, H, W = 2, 7, 120, 160
+    rs = np.random.RandomState(5)
+    vids = rs.randint(0, 256, (n, B, H, W, 3)).astype(np.uint8)
+    boxes0 = [[40 + 10 * b, 30 + 5 * b, 30, 24 + 2 * b] for b in range(B)]
+    res = {}
+    for mode, limit in (("pinned", 2 << 20), ("uploaded", 0)):
+        monkeypatch.setattr(BatchedVitTracker, "ZERO_COPY_MAX_BYTES", limit)
+        for sync in (True, False):
+            bt = BatchedVitTracker(p, B)
+            bt.initialize(vids[0], boxes0)
+            assert bt.frames[0].is_cuda == (mode == "uploaded")
+            outs = []
+            for f in range(1, n):
+                o = bt.track(vids[f], sync=sync)
+                if sync:
+                    outs.append((o["target_bbox"].numpy().copy(), o["confidence"].numpy().copy()))
+            if not sync:
+                outs = [(o["target_bbox"].cpu().numpy(), o["confidence"].cpu().numpy())]
+            res[(mode, sync)] = outs
+    for sync in (True, False):
+        for (b0, c0), (b1, c1) in zip(res[("pinned", sync)], res[("uploaded", sync)]):
+            np.testing.assert_array_equal(b0, b1)
+            np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(res[("pinned", False)][0][0], res[("pinned", True)][-1][0])
+
+
 def test_track_chunk_equals_frame_by_frame_tracking():
     """n frames per graph launch (crop -> forward -> state update, n times, in one captured graph) give, frame by frame, exactly
     what track() gives -- from host frames and from a device buffer, and again after re-initialising (the captured graphs read

@@ -32,6 +32,8 @@ def check_params_geometry(params, nat):
 
 
 class BatchedVitTracker:
+    ZERO_COPY_MAX_BYTES = 2 << 20      # host frames up to this size (all sequences together) are read in place from pinned memory
+
     def __init__(self, params, batch: int):
         import torch
         self.params = params
@@ -81,15 +83,45 @@ class BatchedVitTracker:
             a = np.ascontiguousarray(np.stack(frames) if not isinstance(frames, np.ndarray) else frames)
             if a.dtype != np.uint8 or a.ndim != 4 or a.shape[3] != 3 or a.shape[0] != self.B:
                 raise ValueError(f"frames must be (B={self.B}, H, W, 3) uint8")
-            if self.frames is None or tuple(self.frames[0].shape) != a.shape:
+            zero_copy = a.nbytes <= self.ZERO_COPY_MAX_BYTES
+            if self.frames is None or tuple(self.frames[0].shape) != a.shape or self.frames[0].is_cuda == zero_copy:
                 torch.cuda.current_stream().synchronize()      # nothing may still read the old buffers
-                self.frames = [torch.empty(a.shape, dtype=torch.uint8, device="cuda") for _ in range(2)]
+                if zero_copy:
+                    # A few small frames (the plugin's one-sequence step): no upload at all.  The CPU copies the frame into one of
+                    # two PINNED host slots (230 KB: ~3 us) and the crop kernel reads the pixels it needs over the bus (+1 us on the
+                    # kernel) -- against ~19 us for the blocking copy from pageable memory (tools/zero_copy_probe.py).
+                    self.frames = [torch.empty(a.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+                    self._frames_np = [f.numpy() for f in self.frames]
+                    self._slot_done = [None, None]
+                else:
+                    self.frames = [torch.empty(a.shape, dtype=torch.uint8, device="cuda") for _ in range(2)]
             k = self._slot
             self._slot ^= 1
-            self.frames[k].copy_(torch.from_numpy(a))
+            if zero_copy:
+                if self._slot_done[k] is not None:
+                    self._slot_done[k].synchronize()           # the step that last read this slot (two calls ago) has finished
+                np.copyto(self._frames_np[k], a)
+                self._cur_slot = k
+            else:
+                self.frames[k].copy_(torch.from_numpy(a))
+                self._cur_slot = None
             t = self.frames[k]
         self.hw = (int(t.shape[1]), int(t.shape[2]))
         return t
+
+    def _mark_slot(self, synced=False):
+        """After the launch that reads the current pinned frame slot: an event the next writer of that slot waits for (none when
+        the caller synchronises on this step anyway)."""
+        import torch
+        k = getattr(self, "_cur_slot", None)
+        if k is None:
+            return
+        if synced:
+            self._slot_done[k] = None
+            return
+        if self._slot_done[k] is None:
+            self._slot_done[k] = torch.cuda.Event()
+        self._slot_done[k].record()
 
     def initialize(self, frames, init_boxes):
         """frames: (B,H,W,3) uint8 (numpy, list of arrays or CUDA tensor); init_boxes: (B,4) [x,y,w,h]."""
@@ -105,6 +137,7 @@ class BatchedVitTracker:
         self.states.copy_(torch.as_tensor(boxes))
         self.nat.crop(fr, self.states, self.params.template_factor, self.params.template_size, self.mean, self.std,
                       out=self.z, resize_factor=self.rf)
+        self._mark_slot()
         # The template never changes after this (lib/test/tracker/vit_dist.py:57-60): its patch embedding and block 0's
         # LayerNorm-1 + qkv rows are computed once here (vt_set_template, bit-identical to recomputing them every frame);
         # graphs captured with z = None read that cache, so they stay valid across re-initialisation.
@@ -126,6 +159,7 @@ class BatchedVitTracker:
             # captured graph per slot -- one launch instead of three, no launch gaps inside the step
             g, rec, host, _ = self._chunk_graph(fr.unsqueeze(0), to_host=sync)
             g.replay()
+            self._mark_slot(synced=sync)
             if sync:
                 r = self._records(rec, host)
                 return {"target_bbox": r[0, :, :4], "confidence": r[0, :, 4].float()}

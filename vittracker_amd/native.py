@@ -361,22 +361,23 @@ class Model:
 
     # ---- pre / post steps of track() on the device
     def crop(self, frames, states, factor, out_size, mean, std, out=None, resize_factor=None, stream=None):
-        """frames (B,H,W,3) uint8 cuda, states (B,4) float64 cuda -> (crops (B,3,T,T) fp32, resize_factor (B) fp64)."""
+        """frames (B,H,W,3) uint8 cuda -- or PINNED host memory, which the kernel reads over the bus (a few sequences: no upload) --,
+        states (B,4) float64 cuda -> (crops (B,3,T,T) fp32, resize_factor (B) fp64)."""
         import torch
-        if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+        if not ((frames.is_cuda or frames.is_pinned()) and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
                 and frames.shape[3] == 3):
-            raise VtError("frames must be a contiguous (B,H,W,3) uint8 tensor on the GPU")
+            raise VtError("frames must be a contiguous (B,H,W,3) uint8 tensor on the GPU (or in pinned host memory)")
         if not (states.is_cuda and states.dtype == torch.float64 and states.is_contiguous()):
             raise VtError("states must be a contiguous (B,4) float64 tensor on the GPU")
         B, H, W, _ = frames.shape
         if tuple(states.shape) != (B, 4):
             raise VtError(f"states must be ({B},4) for {B} frames, got {tuple(states.shape)}")
         if out is None:
-            out = torch.empty(B, 3, out_size, out_size, device=frames.device)
+            out = torch.empty(B, 3, out_size, out_size, device=states.device)
         elif tuple(out.shape) != (B, 3, out_size, out_size):
             raise VtError(f"crop output must be ({B},3,{out_size},{out_size}), got {tuple(out.shape)}")
         if resize_factor is None:
-            resize_factor = torch.empty(B, dtype=torch.float64, device=frames.device)
+            resize_factor = torch.empty(B, dtype=torch.float64, device=states.device)
         elif tuple(resize_factor.shape) != (B,) or resize_factor.dtype != torch.float64 or not resize_factor.is_cuda:
             raise VtError(f"resize_factor must be a ({B},) float64 tensor on the GPU")
         m3 = (C.c_float * 3)(*[float(v) for v in mean])
