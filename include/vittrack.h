@@ -152,6 +152,15 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
                            int32_t search_size, int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev,
                            double* record);
 
+/* The whole per-frame step of Vit_dist.track() (lib/test/tracker/vit_dist.py:87-148) in ONE call: vt_crop of the search region
+ * (search_size of the model's config; crops_dev = a (B,3,S,S) float workspace of the caller) -> the network on the cached
+ * template (vt_set_template first) -> vt_update_state_record.  Same kernels and results as the three calls; with the
+ * small-batch head form the decode kernel runs the tail itself (one launch less per step).  record may be NULL.
+ * vit_48 path only. */
+int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, double* states_dev, double factor, const float* mean3,
+                  const float* std3, int32_t B, void* stream, float* crops_dev, double* resize_factor_dev, const vt_outputs* out,
+                  int32_t margin, double* record);
+
 /* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,
                      const vt_outputs* out, vt_graph** g);

@@ -141,6 +141,44 @@ def test_batched_tracker_equals_independent_plugin_trackers():
     np.testing.assert_array_equal(last["target_bbox"].cpu().numpy(), out["target_bbox"].numpy())
 
 
+@pytest.mark.parametrize("geom,B", [(128, 3), (256, 2), (128, 200)])
+def test_track_step_equals_its_three_calls(geom, B):
+    """vt_track_step (crop -> network on the cached template -> tail; the decode kernel runs the tail itself on the small-batch
+    path, the fused heads are followed by the tail kernel) == vt_crop + vt_forward + vt_update_state_record, bit for bit."""
+    import torch
+    from vittracker_amd import native, synth
+    m = native.Model(geom // 2, geom, max_batch=B)
+    m.load_state_dict(synth.synth_state_dict(4, len_z=(geom // 32) ** 2, len_x=(geom // 16) ** 2))
+    H, W = 120, 160
+    rs = np.random.RandomState(8)
+    frames = torch.from_numpy(rs.randint(0, 256, (3, B, H, W, 3)).astype(np.uint8)).cuda()
+    boxes = np.stack([[30 + (b % 40), 20 + (b % 30), 30 + (b % 7), 24 + (b % 5)] for b in range(B)]).astype(np.float64)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    res = []
+    for fused in (False, True):
+        states = torch.from_numpy(boxes).cuda()
+        z, rf = m.crop(frames[0], states, 2.0, geom // 2, mean, std)
+        m.set_template(z)
+        x = torch.empty(B, 3, geom, geom, device="cuda")
+        out = native.Outputs(B, geom // 16, "cuda")
+        rec = torch.zeros(B, 5, dtype=torch.float64, device="cuda")
+        recs = []
+        for f in (1, 2):
+            if fused:
+                m.track_step(frames[f], states, 4.0, mean, std, x, rf, out, record=rec)
+            else:
+                m.crop(frames[f], states, 4.0, geom, mean, std, out=x, resize_factor=rf)
+                m.forward(None, x, out=out)
+                m.update_state_record(out.hann_boxes, out.conf, rf, states, rec, geom, H, W, margin=10)
+            recs.append((rec.clone(), states.clone(), out.hann_boxes.clone(), out.pred_boxes.clone(), out.score_map.clone()))
+        res.append(recs)
+    for a, b in zip(*res):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    assert torch.isfinite(res[1][-1][0]).all() and not torch.equal(res[1][0][1], res[1][1][1])
+    m.close()
+
+
 def test_frames_read_in_place_from_pinned_memory_equal_uploaded_frames(monkeypatch):
     """Small host frames are copied by the CPU into pinned slots that the crop kernel reads over the bus (no upload); larger ones are
     uploaded into device slots.  Same kernels on the same pixels: boxes and confidences must be identical, with and without a

@@ -199,11 +199,9 @@ class BatchedVitTracker:
         with torch.cuda.graph(g, stream=side):
             cs = torch.cuda.current_stream()
             for i in range(n):
-                self.nat.crop(buf[i], self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
-                              out=self.x, resize_factor=self.rf, stream=cs)
-                self.nat.forward(None, self.x, out=self.out, stream=cs)
-                self.nat.update_state_record(self.out.hann_boxes, self.out.conf, self.rf, self.states, rec[i], self.params.search_size, H, W,
-                                             margin=10, stream=cs)
+                # vt_track_step = vt_crop -> vt_forward on the cached template -> vt_update_state_record in one library call
+                self.nat.track_step(buf[i], self.states, self.params.search_factor, self.mean, self.std, self.x, self.rf, self.out,
+                                    record=rec[i], margin=10, stream=cs)
         torch.cuda.current_stream().wait_stream(side)
         self._chunk_graphs[key] = (g, rec, host, buf)   # buf: the graph's kernels read it, keep it alive
         return self._chunk_graphs[key]

@@ -445,9 +445,19 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     }
 }
 
+// tail (optional): the tracker's map back / clip / state update / record of vt_track_step, run by the decode kernel itself
 int run_decode(vt_model* m, hipStream_t st, const float* score, const float* size, const float* offset,
-               const float* window, int B, float* pred, float* hann, float* conf) {
-    hipLaunchKernelGGL(vth::decode_kernel, dim3(B), dim3(64), 0, st, score, size, offset, window, m->F, pred, hann, conf);
+               const float* window, int B, float* pred, float* hann, float* conf, const TrackTail* tail = nullptr) {
+    hipLaunchKernelGGL(vth::decode_kernel, dim3(B), dim3(64), 0, st, score, size, offset, window, m->F, pred, hann, conf,
+                       tail ? *tail : TrackTail{}, tail ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+// the tail as its own launch (heads that decode inside their kernel)
+int run_tail(hipStream_t st, const float* hann, const float* conf, int B, const TrackTail& t) {
+    hipLaunchKernelGGL(vtt::update_state_kernel, dim3((B + 63) / 64), dim3(64), 0, st, hann, t.resize_factor, t.search_size, t.H, t.W,
+                       t.margin, B, t.states, conf, t.record);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -456,7 +466,7 @@ int run_decode(vt_model* m, hipStream_t st, const float* score, const float* siz
 // form -> split form: B=1 86.0 -> 78.6, B=8 96.6 -> 91.5, B=16 110.3 -> 103.5, B=32 135.2 -> 132.9, B=64 181.7 -> 186.2
 constexpr int HEAD_SPLIT_MAX_B = 32;
 
-int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o, size_t f0 = 0) {
+int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_outputs* o, size_t f0 = 0, const TrackTail* tail = nullptr) {
     // outputs of the slice starting at frame f0 (feat already points at the slice)
     const size_t n = (size_t)m->len_x;
     float* score = ((o && o->score_map) ? o->score_map : m->score.p) + f0 * n;
@@ -474,7 +484,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         if (m->skip_head) go(&vth::head_fused_kernel<8, true>);
         else go(&vth::head_fused_kernel<8, false>);
         HIP_TRY(hipGetLastError());
-        return VT_OK;
+        return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
     }
     if (m->F == 8) {
         if (m->skip_head)
@@ -492,7 +502,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         if (m->skip_head) go(&vth::head_seq_kernel<16, 8, true>);
         else go(&vth::head_seq_kernel<16, 8, false>);
         HIP_TRY(hipGetLastError());
-        return VT_OK;
+        return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
     } else if (m->F == 16 && !m->skip_head && B <= m->head_m1_frames && f0 == 0 &&
                (m->head_split < 0 ? B <= HEAD_SPLIT_MAX_B : m->head_split != 0)) {
         // small batches: conv1 of every tower over four row strips (12 workgroups per frame), then the rest of each tower
@@ -511,7 +521,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         return fail(VT_ERR_ARG, "unsupported feat_sz " + std::to_string(m->F));
     }
     HIP_TRY(hipGetLastError());
-    return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf);
+    return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf, tail);
 }
 
 // ViT-Base: towers + conv5 in vitb.hip, then the same decode kernel (first-index argmax, raw and Hann-windowed)
@@ -1052,6 +1062,23 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
                        hann_boxes_dev, resize_factor_dev, search_size, H, W, margin, B, states_dev, conf_dev, record);
     HIP_TRY(hipGetLastError());
     return VT_OK;
+}
+
+int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, double* states_dev, double factor, const float* mean3,
+                  const float* std3, int32_t B, void* stream, float* crops_dev, double* resize_factor_dev, const vt_outputs* out,
+                  int32_t margin, double* record) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (m->vb) return fail(VT_ERR_ARG, "vt_track_step is implemented for the vit_48 path only");
+    if (m->tmpl_frames < B)
+        return fail(VT_ERR_STATE, "vt_track_step needs vt_set_template for at least " + std::to_string(B) + " frames first");
+    if (!states_dev) return fail(VT_ERR_ARG, "null argument");
+    if ((rc = vt_crop(m, frames, H, W, states_dev, factor, m->cfg.search_size, mean3, std3, B, stream, crops_dev, resize_factor_dev))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = run_stem(m, nullptr, crops_dev, B, st, m->tokens_c.p, 0, 1))) return rc;
+    if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
+    const TrackTail tail{resize_factor_dev, states_dev, record, m->cfg.search_size, H, W, margin};
+    return run_head(m, m->feat.p, B, st, out, 0, &tail);
 }
 
 // One slice [f0, f0 + nb) of a batch through the whole step, on stream st.

@@ -149,3 +149,45 @@ __device__ __forceinline__ float sigmoid_clamped(float v) {
     float y = 1.0f / (1.0f + expf(-v));
     return fminf(fmaxf(y, 1e-4f), 1.0f - 1e-4f);
 }
+
+// ---- the tail of Vit_dist.track() for one sequence (lib/test/tracker/vit_dist.py:107-111,150-156; clip_box,
+// lib/utils/box_ops.py:97-106).  Shared by update_state_kernel (vt_track.h) and the decode kernel's fused form (vt_head.h).
+struct TrackTail {
+    const double* resize_factor;   // (B) from crop_kernel
+    double* states;                // (B,4) [x,y,w,h], updated in place
+    double* record;                // optional (B,5) [x,y,w,h,confidence]: device or device-mapped pinned host memory
+    int search_size, H, W, margin;
+};
+
+__device__ __forceinline__ void update_state_one(int b, const float (&hann_box)[4], float conf, const TrackTail& t) {
+    const double rf = t.resize_factor[b];
+    // (pred_boxes.mean(0) * search_size / resize_factor).tolist(): float32 arithmetic, then Python floats
+    double p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = (double)((hann_box[k] * (float)t.search_size) / (float)rf);
+    // map_box_back (lib/test/tracker/vit_dist.py:150-156)
+    const double sx = t.states[4 * b + 0], sy = t.states[4 * b + 1], sw = t.states[4 * b + 2], sh = t.states[4 * b + 3];
+    const double cx_prev = sx + 0.5 * sw, cy_prev = sy + 0.5 * sh;
+    const double half_side = 0.5 * t.search_size / rf;
+    const double cx_real = p[0] + (cx_prev - half_side), cy_real = p[1] + (cy_prev - half_side);
+    double bx1 = cx_real - 0.5 * p[2], by1 = cy_real - 0.5 * p[3];
+    const double w = p[2], h = p[3];
+    // clip_box(box, H, W, margin) (lib/utils/box_ops.py:97-106)
+    double bx2 = bx1 + w, by2 = by1 + h;
+    bx1 = fmin(fmax(0.0, bx1), (double)(t.W - t.margin));
+    bx2 = fmin(fmax((double)t.margin, bx2), (double)t.W);
+    by1 = fmin(fmax(0.0, by1), (double)(t.H - t.margin));
+    by2 = fmin(fmax((double)t.margin, by2), (double)t.H);
+    const double nw = fmax((double)t.margin, bx2 - bx1), nh = fmax((double)t.margin, by2 - by1);
+    t.states[4 * b + 0] = bx1;
+    t.states[4 * b + 1] = by1;
+    t.states[4 * b + 2] = nw;
+    t.states[4 * b + 3] = nh;
+    if (t.record != nullptr) {
+        t.record[5 * b + 0] = bx1;
+        t.record[5 * b + 1] = by1;
+        t.record[5 * b + 2] = nw;
+        t.record[5 * b + 3] = nh;
+        t.record[5 * b + 4] = (double)conf;
+    }
+}

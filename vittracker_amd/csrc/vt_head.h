@@ -245,7 +245,9 @@ __global__ __launch_bounds__(64) void decode_kernel(const float* __restrict__ sc
                                                     const float* __restrict__ offset,
                                                     const float* __restrict__ window, int F,
                                                     float* __restrict__ pred, float* __restrict__ hann,
-                                                    float* __restrict__ conf) {
+                                                    float* __restrict__ conf, TrackTail tail, int has_tail) {
+    // has_tail: lane 0 also runs the tracker's tail on its frame (vt_track_step: map back, clip, state update, record) --
+    // one launch less per step on the small-batch path, where every kernel boundary is a latency
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = F * F;
     float v0 = -3.0e38f, v1 = -3.0e38f;
@@ -275,11 +277,15 @@ __global__ __launch_bounds__(64) void decode_kernel(const float* __restrict__ sc
             pred[b * 4 + 2] = sz[i0];
             pred[b * 4 + 3] = sz[n + i0];
         }
-        if (hann != nullptr && window != nullptr) {
-            hann[b * 4 + 0] = ((float)(i1 % F) + of[i1]) / fF;
-            hann[b * 4 + 1] = ((float)(i1 / F) + of[n + i1]) / fF;
-            hann[b * 4 + 2] = sz[i1];
-            hann[b * 4 + 3] = sz[n + i1];
+        if (window != nullptr && (hann != nullptr || has_tail)) {
+            const float hb[4] = {((float)(i1 % F) + of[i1]) / fF, ((float)(i1 / F) + of[n + i1]) / fF, sz[i1], sz[n + i1]};
+            if (hann != nullptr) {
+                hann[b * 4 + 0] = hb[0];
+                hann[b * 4 + 1] = hb[1];
+                hann[b * 4 + 2] = hb[2];
+                hann[b * 4 + 3] = hb[3];
+            }
+            if (has_tail) update_state_one(b, hb, v0, tail);
         }
         if (conf != nullptr) conf[b] = v0;
     }

@@ -127,35 +127,9 @@ __global__ void update_state_kernel(const float* __restrict__ hann_boxes, const 
                                     const float* __restrict__ conf, double* __restrict__ record) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const double rf = resize_factor[b];
-    // (pred_boxes.mean(0) * search_size / resize_factor).tolist(): float32 arithmetic, then Python floats
-    double p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) p[k] = (double)((hann_boxes[4 * b + k] * (float)search_size) / (float)rf);
-    // map_box_back (lib/test/tracker/vit_dist.py:150-156)
-    const double sx = states[4 * b + 0], sy = states[4 * b + 1], sw = states[4 * b + 2], sh = states[4 * b + 3];
-    const double cx_prev = sx + 0.5 * sw, cy_prev = sy + 0.5 * sh;
-    const double half_side = 0.5 * search_size / rf;
-    const double cx_real = p[0] + (cx_prev - half_side), cy_real = p[1] + (cy_prev - half_side);
-    double bx1 = cx_real - 0.5 * p[2], by1 = cy_real - 0.5 * p[3];
-    const double w = p[2], h = p[3];
-    // clip_box(box, H, W, margin) (lib/utils/box_ops.py:97-106)
-    double bx2 = bx1 + w, by2 = by1 + h;
-    bx1 = fmin(fmax(0.0, bx1), (double)(W - margin));
-    bx2 = fmin(fmax((double)margin, bx2), (double)W);
-    by1 = fmin(fmax(0.0, by1), (double)(H - margin));
-    by2 = fmin(fmax((double)margin, by2), (double)H);
-    states[4 * b + 0] = bx1;
-    states[4 * b + 1] = by1;
-    states[4 * b + 2] = fmax((double)margin, bx2 - bx1);
-    states[4 * b + 3] = fmax((double)margin, by2 - by1);
-    if (record != nullptr) {
-        record[5 * b + 0] = bx1;
-        record[5 * b + 1] = by1;
-        record[5 * b + 2] = fmax((double)margin, bx2 - bx1);
-        record[5 * b + 3] = fmax((double)margin, by2 - by1);
-        record[5 * b + 4] = conf != nullptr ? (double)conf[b] : 0.0;
-    }
+    const float hb[4] = {hann_boxes[4 * b + 0], hann_boxes[4 * b + 1], hann_boxes[4 * b + 2], hann_boxes[4 * b + 3]};
+    const TrackTail t{resize_factor, states, record, search_size, H, W, margin};
+    update_state_one(b, hb, conf != nullptr ? conf[b] : 0.f, t);
 }
 
 }  // namespace vtt

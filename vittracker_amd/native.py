@@ -23,7 +23,7 @@ SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
-    "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record",
+    "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record", "vt_track_step",
 ]
 
 
@@ -92,6 +92,7 @@ def lib(precision: str = "f32"):
     L.vt_update_state.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.vt_update_state_record.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.vt_set_template.argtypes = [vp, vp, i32, vp]
+    L.vt_track_step.argtypes = [vp, vp, i32, i32, vp, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp, vp, i32, vp]
     if precision == "f32":
         _lib = L
     else:
@@ -412,6 +413,33 @@ class Model:
                                             H, W, margin, B, _stream(stream), C.c_void_p(states.data_ptr()),
                                             C.c_void_p(record.data_ptr())), "vt_update_state_record", self._L)
         return record
+
+    def track_step(self, frames, states, factor, mean, std, x, resize_factor, out: Outputs, record=None, margin=10, stream=None):
+        """crop -> network on the cached template -> map back / clip / state update (-> record) as ONE library call (vt_track_step):
+        the same kernels as crop() + forward(None, x) + update_state_record(), with the tail fused into the decode kernel on the
+        small-batch path.  frames (B,H,W,3) uint8 on the GPU or pinned; x: the (B,3,S,S) crop workspace; states (B,4) / resize_factor
+        (B,) float64 on the GPU; record: optional (B,5) float64, GPU or pinned."""
+        import torch
+        if not ((frames.is_cuda or frames.is_pinned()) and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+                and frames.shape[3] == 3):
+            raise VtError("frames must be a contiguous (B,H,W,3) uint8 tensor on the GPU (or in pinned host memory)")
+        B, H, W, _ = frames.shape
+        if self._check_x_only(x) != B:
+            raise VtError(f"crop workspace is for {x.shape[0]} frames, got {B}")
+        if (tuple(states.shape) != (B, 4) or states.dtype != torch.float64 or not states.is_cuda or not states.is_contiguous()
+                or tuple(resize_factor.shape) != (B,) or resize_factor.dtype != torch.float64 or not resize_factor.is_cuda):
+            raise VtError(f"track_step wants states ({B},4) and resize_factor ({B},) float64 on the GPU")
+        if record is not None and (tuple(record.shape) != (B, 5) or record.dtype != torch.float64 or not record.is_contiguous()
+                                   or not (record.is_cuda or record.is_pinned())):
+            raise VtError(f"record must be a contiguous ({B},5) float64 tensor on the GPU or in pinned host memory")
+        self._check_out(out, B)
+        st = out.struct()
+        m3 = (C.c_float * 3)(*[float(v) for v in mean])
+        s3 = (C.c_float * 3)(*[float(v) for v in std])
+        _check(self._L.vt_track_step(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor), m3, s3, B,
+                                   _stream(stream), _ptr(x), C.c_void_p(resize_factor.data_ptr()), C.byref(st), margin,
+                                   C.c_void_p(record.data_ptr()) if record is not None else None), "vt_track_step", self._L)
+        return out
 
     def cal_bbox(self, score, size, offset, stream=None):
         import torch
