@@ -64,6 +64,8 @@ class BatchedVitTracker:
         self._chunk_graphs = {}      # (frame buffer address, n, H, W) -> whole-step graph of n frames (track_chunk)
         self._chunk_buf = None
         self.frames = None
+        self._fast_shape = None
+        self._fast = [None, None]    # per pinned frame slot: (numpy view of the slot, its whole-step graph, numpy view of its pinned record)
         self._slot = 0
         self.hw = None
         self.frame_id = 0
@@ -86,6 +88,7 @@ class BatchedVitTracker:
             zero_copy = a.nbytes <= self.ZERO_COPY_MAX_BYTES
             if self.frames is None or tuple(self.frames[0].shape) != a.shape or self.frames[0].is_cuda == zero_copy:
                 torch.cuda.current_stream().synchronize()      # nothing may still read the old buffers
+                self._fast = [None, None]
                 if zero_copy:
                     # A few small frames (the plugin's one-sequence step): no upload at all.  The CPU copies the frame into one of
                     # two PINNED host slots (230 KB: ~3 us) and the crop kernel reads the pixels it needs over the bus (+1 us on the
@@ -146,6 +149,30 @@ class BatchedVitTracker:
             self.graph, _ = self.nat.capture(None, self.x, self.out)
         self.frame_id = 0
 
+    def track_record(self, frames):
+        """track(frames, sync=True) for callers that want the raw per-sequence records: a (B,5) float64 numpy array
+        [x, y, w, h, confidence] (a view of the step's pinned record when the fast path applies: valid until the call after next).
+        The plugin tracker's per-frame call: for host frames that are read in place (see _upload) a repeat call is one CPU copy,
+        one graph launch, one stream synchronisation and nothing else."""
+        import torch
+        a = frames
+        if type(a) is np.ndarray and self.frames is not None and a.shape == self._fast_shape and a.dtype == np.uint8 and a.flags.c_contiguous:
+            k = self._slot
+            ent = self._fast[k]
+            if ent is not None:
+                if self.graph is None:
+                    raise VtError("track before initialize")
+                self._slot = k ^ 1
+                np.copyto(ent[0], a)
+                self._cur_slot = k
+                self._slot_done[k] = None
+                ent[1].replay()
+                torch.cuda.current_stream().synchronize()
+                self.frame_id += 1
+                return ent[2][0]
+        out = self.track(frames, sync=True)
+        return torch.cat([out["target_bbox"], out["confidence"].double().view(-1, 1)], dim=1).numpy()
+
     def track(self, frames, sync: bool = True):
         """Advance every sequence by one frame.  Returns {'target_bbox': (B,4) float64, 'confidence': (B,)}
         as CPU tensors when sync=True, else the device tensors (valid until the next call)."""
@@ -160,6 +187,10 @@ class BatchedVitTracker:
             g, rec, host, _ = self._chunk_graph(fr.unsqueeze(0), to_host=sync)
             g.replay()
             self._mark_slot(synced=sync)
+            k = getattr(self, "_cur_slot", None)
+            if sync and k is not None and host is None and self._fast[k] is None:      # pinned frame slot + pinned record: the fast path of track_record
+                self._fast[k] = (self._frames_np[k], g, rec.numpy())
+                self._fast_shape = tuple(self._frames_np[k].shape)
             if sync:
                 r = self._records(rec, host)
                 return {"target_bbox": r[0, :, :4], "confidence": r[0, :, 4].float()}

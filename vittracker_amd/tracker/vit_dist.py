@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import os
 
+import numpy as np
+
 from ..host_ops import Preprocessor, clip_box, hann2d, sample_target
 from ..batched import check_params_geometry
 from ..model import build_ostrack_dist
@@ -125,14 +127,14 @@ class Vit_dist(BaseTracker):
         H, W, _ = image.shape
         self.frame_id += 1
         if self._bt is not None:
-            out = self._bt.track(image[None])                # sync=True: state and confidence on the host
-            self.state = out["target_bbox"][0].tolist()
+            rec = self._bt.track_record(image[None])[0].tolist()      # [x, y, w, h, confidence] of this frame, on the host
+            self.state = rec[:4]
             if self.save_all_boxes:
                 # rare mode: two more small copies for the un-clipped box (the windowed decode and this frame's resize factor)
                 pred_boxes = self._bt.out.hann_boxes.cpu().view(-1, 4)
                 resize_factor = float(self._bt.rf.cpu()[0])
                 return {"target_bbox": self.state, "all_boxes": self._all_boxes(pred_boxes, resize_factor)}
-            return {"target_bbox": self.state, "confidence": float(out["confidence"][0])}
+            return {"target_bbox": self.state, "confidence": float(np.float32(rec[4]))}
         x_patch_arr, resize_factor, x_amask_arr = sample_target(image, self.state, self.params.search_factor,
                                                                 output_sz=self.params.search_size)
         search = self.preprocessor.process(x_patch_arr, x_amask_arr)
