@@ -48,7 +48,11 @@ struct FusedGeo {                       // TX = 128, TZ = 64
     static constexpr int NPIX3Z = round16((TZ / 8 + 1) * (TZ / 8 + 1));    // 96
     // small constants, copied once: layer-2 weight images (5 x 64 f4), b2 (4 f4), b3 (8 f4), b4 (12 f4)
     static constexpr int CONST_F4 = 5 * 64 + 4 + 8 + 12;
-    static constexpr int LDS_F4 = 2 * RING + 3 * NPIX2X + 3 * NPIX2Z + CONST_F4;
+    // per-chunk map offsets of layers 3 / 4 as tables [crop][quad q][chunk] (ints): s2_chunk_off costs ~15 VALU instructions per
+    // chunk and lane -- 220 of them around layer 3's 84 MFMAs, on the pipe the MFMAs need -- a table entry one LDS read
+    static constexpr int OFF3 = 8, OFF4 = 16;                              // chunks per table row (7 and 14 used)
+    static constexpr int OFFTAB_F4 = (2 * 4 * OFF3 + 2 * 4 * OFF4) / 4;    // 48
+    static constexpr int LDS_F4 = 2 * RING + 3 * NPIX2X + 3 * NPIX2Z + CONST_F4 + OFFTAB_F4;
     static constexpr int LDS_BYTES = LDS_F4 * 16;                          // 144,768
     static_assert(6 * NPIX3X + 6 * NPIX3Z <= 2 * RING, "layer-3 maps must fit in the rings");
     static_assert((2 * R2X) * (TX / 4) == 512 && (2 * R2Z) * (TZ / 4) == 512, "one pixel pair per thread of a group");
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* const cb2 = reinterpret_cast<const float*>(cw2 + 5 * 64);   // 16 floats
     const float* const cb3 = cb2 + 16;                                       // 32
     const float* const cb4 = cb3 + 32;                                       // 48
+    int* const otab = reinterpret_cast<int*>(cw2 + G::CONST_F4);             // [x | z][4][OFF3] then [x | z][4][OFF4]
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -305,7 +310,16 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     }
     {   // zero only what is read without ever being written: the top rows of the rings,
         // row 0 and column -1 of the layer-2 maps (column -1 of the rings is cleared per band in layer1)
-        if (t < 384) {}
+        if (t < 192) {                                                  // the layer-3 / layer-4 offset tables, one entry per thread
+            const bool l4 = t >= 64;
+            const int e = l4 ? t - 64 : t, per = l4 ? 4 * G::OFF4 : 4 * G::OFF3;
+            const bool isz = e >= per;
+            const int r = isz ? e - per : e, qq = l4 ? r / G::OFF4 : r / G::OFF3, c = l4 ? r - qq * G::OFF4 : r - qq * G::OFF3;
+            int v;
+            if (!l4) v = isz ? s2_chunk_off<3>(c, qq, G::NPIX2Z, G::TZ / 4 + 1, G::TZ / 8) : s2_chunk_off<3>(c, qq, G::NPIX2X, G::TX / 4 + 1, G::TX / 8);
+            else v = isz ? s2_chunk_off<6>(c, qq, G::NPIX3Z, G::TZ / 8 + 1, G::TZ / 16) : s2_chunk_off<6>(c, qq, G::NPIX3X, G::TX / 8 + 1, G::TX / 16);
+            otab[t] = v;
+        } else if (t < 384) {}
         else if (t >= 384 && t < 384 + 2 * 65) {                        // ring B, row 0 (first used by x0: image top)
             const int e = t - 384, pl = e / 65, col = e - pl * 65;
             ring0[G::RING + pl * G::NPIX1X + col] = splat4(0.f);
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             if (do_x) layer1(bx1, v);                   stamp(); __syncthreads(); stamp();   // 2: L1(x1)
             l2_and_fetch(bx1, l2 && do_x, bx3, do_x);   stamp(); __syncthreads(); stamp();   // 3: L2(x1), x3 requested
             if (do_x) layer1(bx3, v);                   stamp(); __syncthreads(); stamp();   // 4: L1(x3)
+            load_w3();     // the layer-3 weights' L2 round trip runs under this interval (no prefetched band is live any more)
             if (l2 && do_x) layer2(bx3);                stamp(); __syncthreads(); stamp();   // 5: L2(x3)
         } else {
             stamp(); __syncthreads(); stamp();   // 0: (x0 requested at kernel start)
@@ -361,9 +376,9 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             l2_and_fetch(bx0, l2 && do_x, bx2, do_x);   stamp(); __syncthreads(); stamp();   // 2: L2(x0), x2 requested
             if (do_x) layer1(bx2, v);                   stamp(); __syncthreads(); stamp();   // 3: L1(x2)
             if (l2 && do_x) layer2(bx2);                stamp(); __syncthreads(); stamp();   // 4: L2(x2)
+            load_w3();
             __syncthreads();   // 5
         }
-        load_w3();
     }
 
     // ---- layer 3 (12 -> 24, Hardswish) on the whole maps, all 16 waves -------------------------------------
@@ -390,7 +405,13 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
 #pragma unroll
                 for (int i = 0; i < 2; ++i) base[i] = 2 * ((wave >> 1) + 8 * i) * P2 + px;
                 f4 acc[2][1] = {{bv3}, {bv3}};
-                auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, G::NPIX2X, P2, H2); };
+                int o3[G::OFF3];
+                {
+                    const int4* tp = reinterpret_cast<const int4*>(otab + q * G::OFF3);
+                    const int4 a = tp[0], bq = tp[1];
+                    o3[0] = a.x; o3[1] = a.y; o3[2] = a.z; o3[3] = a.w; o3[4] = bq.x; o3[5] = bq.y; o3[6] = bq.z; o3[7] = bq.w;
+                }
+                auto off3 = [&](int c) { return o3[c]; };
                 vtc::mma_pass<1, 2, NCH3, NCH3>(m2, base, w3a, 0, off3, acc);
                 if (16 * ot3 + 4 * q < 24) {
 #pragma unroll
@@ -409,7 +430,13 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                 const int op = 16 * (wave >> 1) + px, y = op >> 3, x = op & 7;
                 int base[1] = {2 * y * P2 + x};
                 f4 acc[1][1] = {{bv3}};
-                auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, G::NPIX2Z, P2, H2); };
+                int o3[G::OFF3];
+                {
+                    const int4* tp = reinterpret_cast<const int4*>(otab + 4 * G::OFF3 + q * G::OFF3);
+                    const int4 a = tp[0], bq = tp[1];
+                    o3[0] = a.x; o3[1] = a.y; o3[2] = a.z; o3[3] = a.w; o3[4] = bq.x; o3[5] = bq.y; o3[6] = bq.z; o3[7] = bq.w;
+                }
+                auto off3 = [&](int c) { return o3[c]; };
                 vtc::mma_pass<1, 1, NCH3, NCH3>(m2 + M2Z_OFF, base, w3a, 0, off3, acc);
                 if (16 * ot3 + 4 * q < 24) {
                     f4 r = acc[0][0];
@@ -435,7 +462,16 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         int base[1] = {2 * y * P3 + x};
         f4 acc[1][1] = {{ld4(cb4 + 16 * ot + 4 * q)}};
         const f4 pe = ld4((is_z ? pos_z : pos_x) + (size_t)op * 48 + 16 * ot + 4 * q);   // requested before the MFMAs
-        auto off4 = [&](int c) { return s2_chunk_off<6>(c, q, npix3, P3, H3); };
+        int o4[G::OFF4];
+        {
+            const int4* tp = reinterpret_cast<const int4*>(otab + 2 * 4 * G::OFF3 + (is_z ? 4 * G::OFF4 : 0) + q * G::OFF4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int4 a = tp[i];
+                o4[4 * i] = a.x; o4[4 * i + 1] = a.y; o4[4 * i + 2] = a.z; o4[4 * i + 3] = a.w;
+            }
+        }
+        auto off4 = [&](int c) { return o4[c]; };
         vtc::mma_pass<1, 1, NCH4, NCH4>(map3, base, w4a, 0, off4, acc);
         st4(tokens + ((size_t)b * L + (is_z ? 0 : len_z) + op) * 48 + 16 * ot + 4 * q, acc[0][0] + pe);
     }
