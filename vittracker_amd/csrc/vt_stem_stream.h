@@ -47,7 +47,11 @@ struct StreamGeo {
     static constexpr int SLOT2 = 3 * imax(np2(TX), np2(TZ));                                 // f4 per L2 slot (3 planes)
     static constexpr int SLOT3 = 6 * imax(np3(TX), np3(TZ));                                 // f4 per L3 slot (6 planes)
     static constexpr int CONST_F4 = 9 * 32 + 4 + 8 + 12;                                     // layer-2 weights for the 4-block MFMA, b2, b3, b4
-    static constexpr int LDS_F4 = 2 * RING + 3 * SLOT2 + 3 * SLOT3 + round16(CONST_F4);
+    // per-chunk map offsets of layers 3 / 4 as tables [x | z][quad q][chunk] (ints), as in stem_fused: s2_chunk_off is ~15 VALU
+    // instructions per chunk and lane, 21 chunks per interval on the waves that carry the interval's longest MFMA chains
+    static constexpr int OFF3 = 8, OFF4 = 16;                                                // two 16-bit offsets per int: rows of 4 / 8 ints
+    static constexpr int OFFTAB_F4 = (2 * 4 * OFF3 + 2 * 4 * OFF4) / 8;                      // 24
+    static constexpr int LDS_F4 = 2 * RING + 3 * SLOT2 + 3 * SLOT3 + round16(CONST_F4) + OFFTAB_F4;
     static constexpr int LDS_BYTES = LDS_F4 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(r2(TX) % 4 == 0 && r2(TZ) % 4 == 0, "a band holds whole token rows");
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
     const float* const cb2 = reinterpret_cast<const float*>(cw2 + 9 * 32);            // 16 floats
     const float* const cb3 = cb2 + 16;                                                // 32
     const float* const cb4 = cb3 + 32;                                                // 48
+    int* const otab = reinterpret_cast<int*>(cw2 + round16(G::CONST_F4));             // [x | z][4][OFF3], then [x | z][4][OFF4]
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -112,6 +117,20 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
         else if (t < 9 * 32 + 4) cw2[t] = ld4(b2 + 4 * (t - 288));
         else if (t < 9 * 32 + 12) cw2[t] = ld4(b3 + 4 * (t - 292));
         else if (t < 9 * 32 + 24) cw2[t] = ld4(b4 + 4 * (t - 300));
+        else if (t >= 320 && t < 320 + 4 * G::OFFTAB_F4) {
+            const int e0 = t - 320;                                 // one int = chunks 2 j, 2 j + 1 of a table row
+            const bool l4 = e0 >= 4 * G::OFF3;
+            const int e = l4 ? e0 - 4 * G::OFF3 : e0, per = l4 ? 2 * G::OFF4 : 2 * G::OFF3;      // ints per crop
+            const bool isz = e >= per;
+            const int r = isz ? e - per : e, rowi = l4 ? G::OFF4 / 2 : G::OFF3 / 2, qq = r / rowi, c = 2 * (r - qq * rowi);
+            const int T = isz ? TZ : TX;
+            int v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                v[h] = l4 ? s2_chunk_off<6>(c + h, qq, isz ? G::np3(TZ) : G::np3(TX), (T >> 3) + 1, T >> 4)
+                          : s2_chunk_off<3>(c + h, qq, isz ? G::np2(TZ) : G::np2(TX), (T >> 2) + 1, T >> 3);
+            otab[e0] = v[0] | (v[1] << 16);
+        }
     }
 
     if (wave < 8) {
@@ -293,7 +312,8 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             }
             const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
             f4 acc[2][1] = {{bv3}, {bv3}};
-            auto off3 = [&](int c) { return s2_chunk_off<3>(c, q, J.np2, J.pitch2, J.half2); };
+            const int4 o3 = *reinterpret_cast<const int4*>(otab + (J.is_z ? 2 * G::OFF3 : 0) + q * (G::OFF3 / 2));
+            auto off3 = [&](int c) { const int w = (c >> 1) == 0 ? o3.x : (c >> 1) == 1 ? o3.y : (c >> 1) == 2 ? o3.z : o3.w; return (c & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff); };
 #ifndef VT_SS_PIN3
 #define VT_SS_PIN3 false
 #endif
@@ -318,7 +338,13 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             const int base = 2 * y * J.pitch3 + x;
             const int tk = 16 * J.kb + px;                                      // token index inside this crop
             const f4 pe = ld4((J.is_z ? pos_z : pos_x) + (size_t)tk * 48 + 16 * w4 + 4 * q);   // requested before the MFMAs
-            auto at = [&](int c) { return base + s2_chunk_off<6>(c, q, J.np3, J.pitch3, J.half3); };
+            const int4* const tp4 = reinterpret_cast<const int4*>(otab + 4 * G::OFF3 + (J.is_z ? 2 * G::OFF4 : 0) + q * (G::OFF4 / 2));
+            const int4 o4a = tp4[0], o4b = tp4[1];
+            auto at = [&](int c) {
+                const int4& o = c < 8 ? o4a : o4b;
+                const int j = (c & 7) >> 1, w = j == 0 ? o.x : j == 1 ? o.y : j == 2 ? o.z : o.w;
+                return base + ((c & 1) ? (int)((unsigned)w >> 16) : (w & 0xffff));
+            };
             // One pixel tile x one output tile: a single accumulator would be a chain of 56 dependent MFMAs (40 cycles each instead
             // of 32, and nothing of this wave to fill the gaps).  Even and odd k-chunks go to two accumulators, added at the end;
             // the B operands are read two chunks ahead.
