@@ -19,6 +19,7 @@
 #include "vt_blocks.h"
 #include "vt_blocks_tile.h"
 #include "vt_head.h"
+#include "vt_head3.h"
 #include "vt_stem.h"
 #include "vt_stem_fused.h"
 #include "vt_stem_stream.h"
@@ -70,6 +71,8 @@ struct vt_model {
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
     DevBuf head;                     // 3 * TOWER_STRIDE
+    DevBuf head3;                    // F = 8, fp32 build: the towers' weights as three-piece bf16 images (vt_head3.h)
+    int head_bf3 = 1;                // VT_HEAD_BF3: the towers on the bf16 matrix pipe at fp32 accuracy (F = 8)
     DevBuf window;                   // F*F
     // workspace sized for max_batch
     DevBuf act_x, act_z;             // layer-2 activations, NHWC(12)
@@ -188,6 +191,33 @@ void pack_conv_image(const std::vector<double>& w, int cout, int cin, float* dst
                         if (ic < cin) v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
                     }
                     dst[(((size_t)ot * nch + c) * 64 + l) * 4 + r] = v;
+                }
+}
+
+// The same weights as three-piece bf16 images for vt_head3.h: [oc_tile][chunk pair][piece][64 lanes][8 bf16]; a lane's 8 values
+// are its quad of chunk 2 p, then its quad of chunk 2 p + 1 (zero beyond the last chunk).  w = h + m + l exactly, by truncation
+// (the split the kernels apply to activations: vth3::split3).
+void pack_conv_image3(const std::vector<double>& w, int cout, int cin, uint16_t* dst) {
+    const int nq = (cin + 3) / 4, nqt = 9 * nq, nch = (nqt + 3) / 4, ncp = (nch + 1) / 2, not_ = (cout + 15) / 16;
+    for (int ot = 0; ot < not_; ++ot)
+        for (int cp = 0; cp < ncp; ++cp)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 2 * cp + (e >> 2), r = e & 3;
+                    const int oc = 16 * ot + (l & 15), Q = 4 * c + (l >> 4);
+                    float v = 0.f;
+                    if (oc < cout && c < nch && Q < nqt) {
+                        const int tap = Q / nq, ic = 4 * (Q % nq) + r;
+                        if (ic < cin) v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
+                    }
+                    uint32_t xb, r1b, r2b;
+                    std::memcpy(&xb, &v, 4);
+                    float hf; const uint32_t hb = xb & 0xffff0000u; std::memcpy(&hf, &hb, 4);
+                    const float r1 = v - hf; std::memcpy(&r1b, &r1, 4);
+                    float mf; const uint32_t mb = r1b & 0xffff0000u; std::memcpy(&mf, &mb, 4);
+                    const float r2 = r1 - mf; std::memcpy(&r2b, &r2, 4);
+                    const uint16_t pieces[3] = {(uint16_t)(xb >> 16), (uint16_t)(r1b >> 16), (uint16_t)(r2b >> 16)};
+                    for (int pc = 0; pc < 3; ++pc) dst[((((size_t)ot * ncp + cp) * 3 + pc) * 64 + l) * 8 + e] = pieces[pc];
                 }
 }
 
@@ -475,6 +505,21 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
     float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
+#ifndef VT_F16
+    if (m->F == 8 && m->head_bf3 && !m->skip_head) {       // three-piece bf16 towers (vt_head3.h), same kernel forms by batch size
+        const vth3::u32x4* hw3 = reinterpret_cast<const vth3::u32x4*>(m->head3.p);
+        if (m->head_fused < 0 ? B > 176 : m->head_fused != 0) {
+            hipLaunchKernelGGL(vth3::head_fused3_kernel, dim3(B), dim3(768), vth3::FUSED3_LDS_BYTES, st, feat, m->head.p, hw3, m->window.p,
+                               score, size, offset, pred, hann, conf);
+            HIP_TRY(hipGetLastError());
+            return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
+        }
+        hipLaunchKernelGGL(vth3::head_towers3_kernel, dim3(B, 3), dim3(256), vth3::TOWERS3_LDS_BYTES, st, feat, m->head.p, hw3, score, size,
+                           offset);
+        HIP_TRY(hipGetLastError());
+        return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf, tail);
+    }
+#endif
     if (m->F == 8 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
         // towers + both decodes in one workgroup per frame
         auto go = [&](auto kernel) {
@@ -720,6 +765,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
     m->stem_stream = env_int("VT_STEM_STREAM", -1);
     m->head_fused = env_int("VT_HEAD_FUSED", -1);
+    m->head_bf3 = env_int("VT_HEAD_BF3", 1);
     m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
@@ -772,6 +818,14 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth::head_fused_kernel<8, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth::FusedHeadGeo<8>::LDS_BYTES);
+#ifndef VT_F16
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_fused3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    vth3::FUSED3_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_towers3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    vth3::TOWERS3_LDS_BYTES);
+#endif
         if (e == hipSuccess)
             e = allow_stem_lds();
         if (e == hipSuccess)
@@ -805,7 +859,7 @@ void vt_destroy(vt_model* m) {
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
     m->act_x.release(); m->act_z.release();
-    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
+    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
@@ -911,6 +965,9 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     if ((rc = upload(m->blocks, bp))) return rc;
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
+#ifndef VT_F16
+    std::vector<uint16_t> hp3(m->F == 8 ? (size_t)3 * vth3::TOWER3_STRIDE * 8 : 0, 0);
+#endif
     const char* towers[3] = {"ctr", "offset", "size"};
     const int chans[5] = {48, 32, 16, 8, 4};
     const int woff[4] = {vth::O_W1, vth::O_W2, vth::O_W3, vth::O_W4};
@@ -922,6 +979,12 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             std::vector<double> w, b;
             if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, chans[i + 1], chans[i], w, b))) return rc;
             pack_conv_image(w, chans[i + 1], chans[i], dst + woff[i]);
+#ifndef VT_F16
+            if (m->F == 8) {
+                const int woff3[4] = {vth3::O3_W1, vth3::O3_W2, vth3::O3_W3, vth3::O3_W4};
+                pack_conv_image3(w, chans[i + 1], chans[i], hp3.data() + ((size_t)t * vth3::TOWER3_STRIDE + woff3[i]) * 8);
+            }
+#endif
             for (int o = 0; o < chans[i + 1]; ++o) dst[boff[i] + o] = (float)b[o];
         }
         const int nout = t == 0 ? 1 : 2;
@@ -932,6 +995,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + vth::O_B5, p, nout * sizeof(float));
     }
     if ((rc = upload(m->head, hp))) return rc;
+#ifndef VT_F16
+    if (m->F == 8) {     // the three-piece bf16 images of vt_head3.h (as floats: 16-byte units x 4)
+        std::vector<float> as_f(hp3.size() / 2);
+        std::memcpy(as_f.data(), hp3.data(), hp3.size() * 2);
+        if ((rc = upload(m->head3, as_f))) return rc;
+    }
+#endif
     m->weights_loaded = true;
     return VT_OK;
 }

@@ -1,0 +1,337 @@
+// vt_head3.h -- the CENTER head's towers (F = 8) on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split EXACTLY
+// into three bf16 pieces, x = h + m + l (8 mantissa bits each, by truncation), and a product a b is the six terms
+// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- what is dropped (ml, lm, ll) is below 2^-23 of
+// |a b|, the error of an fp32 MFMA's own rounding (tools/src/probe_bf3.hip: max error / sum |a b| over random 16 x 16 x 16
+// products 2.6e-7 against 3.0e-7 for v_mfma_f32_16x16x4_f32).  Same results contract as vt_head.h (reference:
+// lib/models/layers/head.py:130-201), same maps, same weights -- folded BatchNorm, fp32 bias, ReLU, conv5 and the decode are
+// untouched fp32 code.
+//
+// Why: an fp32 MFMA occupies a SIMD's matrix pipe for 32 cycles per 16 x 16 x 4 block and shares its issue with the VALU; six
+// 16 x 16 x 32 bf16 MFMAs cover EIGHT times the K in 6 x 16 cycles -- 2.6 x less pipe time per fp32-equivalent MAC -- and VALU work
+// of other waves issues beside them.  The towers are 63 % MFMA issue at fp32 (vt_head.h).
+//
+// What changes against vt_head.h:
+//   * LDS maps hold the three pieces as planes of 8-byte entries, uint2 map[piece][channel quad][pixel] (4 bf16 = the four
+//     channels of a quad); a layer's epilogue splits its ReLU'd fp32 results once, readers never convert.  Geometry as Geo<8>
+//     (no halo columns, zero tail).
+//   * weights are split on the host (vt_load_weights) into images [output tile][chunk PAIR][piece][64 lanes][8 bf16]: a lane's
+//     8 values are its quad of chunk 2 p and its quad of chunk 2 p + 1 (the K order inside an MFMA is free as long as both
+//     operands agree), so the fp32 kernels' 16-deep chunks, quad decoding and tap offsets carry over unchanged.
+//   * an odd last chunk pairs with zero weights (the activation read for it clamps to a valid quad, as pad quads always did).
+#pragma once
+#include "vt_head.h"
+
+#ifndef VT_F16
+namespace vth3 {
+
+using vth::C;
+using vth::W1;
+using vth::nchunks;
+using vth::ntiles;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using G = vth::Geo<8>;
+
+constexpr int npairs(int cin) { return (nchunks(cin) + 1) / 2; }
+// weight images per tower, in 16-byte units: [ot][pair][piece][64]
+constexpr int img16(int cin, int cout) { return ntiles(cout) * npairs(cin) * 3 * 64; }
+constexpr int O3_W1 = 0;
+constexpr int O3_W2 = O3_W1 + img16(48, 32);
+constexpr int O3_W3 = O3_W2 + img16(32, 16);
+constexpr int O3_W4 = O3_W3 + img16(16, 8);
+constexpr int TOWER3_STRIDE = O3_W4 + img16(8, 4);      // 16-byte units
+
+// x = h + m + l exactly (truncating pieces: every residual is computed without rounding).  Element r of the result pieces =
+// bf16 bits of x[r]'s piece; two elements per dword, low half first.
+__device__ __forceinline__ void split3(f4 x, u32x2& h, u32x2& m, u32x2& l) {
+    unsigned xb[4], r1b[4], r2b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xb[i] = __float_as_uint(x[i]);
+        const float r1 = x[i] - __uint_as_float(xb[i] & 0xffff0000u);
+        r1b[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(r1b[i] & 0xffff0000u);
+        r2b[i] = __float_as_uint(r2);
+    }
+    h = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+    m = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+    l = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+}
+// the fp32 value back from its pieces (exact: h + m has at most 16 significant bits, + l at most 24)
+__device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {
+    f4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned sh = (i & 1) ? 0u : 16u;
+        const float fh = __uint_as_float((h[i >> 1] << sh) & 0xffff0000u), fm = __uint_as_float((m[i >> 1] << sh) & 0xffff0000u),
+                    fl = __uint_as_float((l[i >> 1] << sh) & 0xffff0000u);
+        v[i] = (fh + fm) + fl;
+    }
+    return v;
+}
+
+// One 3x3 stride-1 conv + bias + ReLU between two piece-planar LDS maps.  Work split over the NW waves of a tower as in
+// vth::HeadConv: a 2-output-tile layer gives each wave one output tile and half of the pixel tiles, 1-tile layers split the
+// pixel tiles.  Weights move in passes of <= MAXP chunk pairs, double-buffered in registers.
+// ACT: waves of the tower that work on a 1-output-tile layer (the others skip it).  Every active wave streams the layer's whole
+// weight image from L2, and with the MFMAs 2.6 x cheaper that stream -- not the matrix pipe -- bounds the towers (1.1 MB per frame
+// with four waves per layer against 405 KB of distinct weights, at ~72 GB/s per CU); two waves with two pixel tiles each halve
+// it for conv2-4 but double those waves' chains: measured 17.3 against 16.6 us, so all four work.
+template <int CIN, int COUT, int NW = 4, int ACT = NW>
+struct HeadConv3 {
+    static constexpr int NQ = CIN / 4, NQO = COUT / 4, NCH = nchunks(CIN), NCP = npairs(CIN), NOT = ntiles(COUT);
+    static constexpr bool SPLIT_OT = NOT == 2;
+    static constexpr int TSTEP = SPLIT_OT ? NW / 2 : ACT;
+    static constexpr int NPT = G::NT / TSTEP;
+    static_assert(G::NT % TSTEP == 0 && NPT >= 1 && NOT <= 2, "work split");
+    static constexpr int MAXP = NCP < 2 ? NCP : 2;      // 2 pairs x 3 pieces x 4 registers, double-buffered = 48 registers (768 threads: 168 per lane)
+    static constexpr int NPASS = (NCP + MAXP - 1) / MAXP;
+    static constexpr int PS_IN = NQ * G::NPIX, PS_OUT = NQO * G::NPIX;       // piece strides (entries)
+    u32x4 a[2][MAXP][3];
+
+    __device__ __forceinline__ const u32x4* wbase(const u32x4* __restrict__ wimg, int wave) const {
+        return wimg + (SPLIT_OT ? (size_t)(wave & 1) * NCP * 192 : 0);
+    }
+    __device__ __forceinline__ void load_pass(const u32x4* __restrict__ wb, int p0, int n, int lane, u32x4 (&dst)[MAXP][3]) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (k < n)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) dst[k][pc] = wb[((size_t)(p0 + k) * 3 + pc) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wimg, int wave, int lane) {
+        load_pass(wbase(wimg, wave), 0, MAXP, lane, a[0]);
+    }
+    // FIRST: run() requests the first pass itself (no prefetch() a layer earlier: the fused kernel's 168 registers per lane do not
+    // hold the next layer's first pass beside this layer's working set)
+    template <bool FIRST = false>
+    __device__ __forceinline__ void run(const u32x2* in_map, u32x2* out_map, const u32x4* __restrict__ wimg,
+                                        const float* __restrict__ bias, int wave, int lane) {
+        if (!SPLIT_OT && wave >= ACT) return;          // `wave` = the wave's slot inside its tower (the caller rotates slots per tower)
+        if constexpr (FIRST) prefetch(wimg, wave, lane);
+        const int q = lane >> 4;
+        const int ot = SPLIT_OT ? (wave & 1) : 0, tfirst = SPLIT_OT ? (wave >> 1) : wave;
+        f4 acc[NPT];
+        const f4 bv = ld4(bias + 16 * ot + 4 * q);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) acc[i] = bv;
+        const u32x4* __restrict__ wb = wbase(wimg, wave);
+        int cb[NPT][3], centre[NPT];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) { G::tap_cols(tfirst + TSTEP * i, lane, cb[i]); centre[i] = cb[i][1] + G::P; }
+        // entry offset (inside a piece) of this lane's quad of 16-deep chunk c for pixel tile i
+        auto at = [&](int c, int i) {
+            int tap, icq;
+            if constexpr (NQ % 4 == 0) { const int cc = c < NCH ? c : NCH - 1; tap = (4 * cc) / NQ; icq = 4 * cc - tap * NQ + q; }
+            else vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            return icq * G::NPIX + dy * G::P + (dx == 0 ? cb[i][0] : (dx == 1 ? cb[i][1] : cb[i][2]));
+        };
+        auto read_b = [&](int cp, u32x4 (&b)[NPT][3]) {
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int o0 = at(2 * cp, i), o1 = at(2 * cp + 1, i);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const u32x2 lo = in_map[pc * PS_IN + o0], hi = in_map[pc * PS_IN + o1];
+                    b[i][pc] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
+        };
+        u32x4 b[2][NPT][3];
+        read_b(0, b[0]);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            constexpr int LASTN = NCP - (NPASS - 1) * MAXP;
+            const int n = p + 1 < NPASS ? MAXP : LASTN;
+            if (p + 1 < NPASS) load_pass(wb, (p + 1) * MAXP, p + 2 < NPASS ? MAXP : LASTN, lane, a[(p + 1) & 1]);
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                if (k >= n) break;
+                const int cp = p * MAXP + k;
+                if (cp + 1 < NCP) {
+                    read_b(cp + 1, b[(cp + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);        // keep the next pair's reads ahead of this pair's MFMAs
+                }
+                const u32x4 (&w)[3] = a[p & 1][k];
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) {
+                    const u32x4 (&x)[3] = b[cp & 1][i];
+                    auto mm = [&](int wp, int xp) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[wp]), __builtin_bit_cast(bf16x8, x[xp]), acc[i], 0, 0, 0);
+                    };
+                    mm(2, 0); mm(0, 2); mm(1, 1); mm(1, 0); mm(0, 1); mm(0, 0);      // smallest terms first
+                }
+            }
+        }
+        if (16 * ot + 4 * q < COUT) {       // skip the zero-padded output channels
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                f4 v = acc[i];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                u32x2 h, m, l;
+                split3(v, h, m, l);
+                const int e = (4 * ot + q) * G::NPIX + centre[i];
+                out_map[e] = h; out_map[PS_OUT + e] = m; out_map[2 * PS_OUT + e] = l;
+            }
+        }
+    }
+};
+
+// LDS entries (uint2) of the maps: input 3 x 12 planes, per tower m1 3 x 8 and m2 3 x 4 planes
+constexpr int IN_E = 3 * (C / 4) * G::NPIX, M1_E = 3 * (W1 / 4) * G::NPIX, M2_E = 3 * 4 * G::NPIX;
+constexpr int TOWERS3_LDS_BYTES = (IN_E + M1_E + M2_E) * 8;
+constexpr int FUSED3_LDS_BYTES = (IN_E + 3 * (M1_E + M2_E)) * 8 + 5 * 64 * 4;
+
+// tokens (B,HW,C) fp32 -> the piece planes of the input map (vit_dist.py:126-129): item = (quad, pixel)
+__device__ __forceinline__ void stage_tokens(u32x2* in_map, const float* __restrict__ feat, int b, int item) {
+    const int icq = item >> 6, pix = item & 63;
+    u32x2 h, m, l;
+    split3(ld4(feat + ((size_t)b * 64 + pix) * C + 4 * icq), h, m, l);
+    const int e = icq * G::NPIX + G::interior(pix >> 3, pix & 7);
+    in_map[e] = h; in_map[(C / 4) * G::NPIX + e] = m; in_map[2 * (C / 4) * G::NPIX + e] = l;
+}
+
+// grid (B, 3), 256 threads: the per-tower form (small batches).  hw: the fp32 parameter block of vt_head.h (biases, conv5); hw3: images.
+__global__ __launch_bounds__(256) void head_towers3_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                          const u32x4* __restrict__ hw3, float* __restrict__ score,
+                                                          float* __restrict__ size, float* __restrict__ offset) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    u32x2* in_map = reinterpret_cast<u32x2*>(sm);
+    u32x2* m1 = in_map + IN_E;
+    u32x2* m2 = m1 + M1_E;
+    const int b = blockIdx.x, t = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
+    const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
+    HeadConv3<C, W1> c1;
+    HeadConv3<W1, 16> c2;
+    HeadConv3<16, 8> c3;
+    HeadConv3<8, 4> c4;
+    c1.prefetch(tw3 + O3_W1, wave, lane);
+    for (int i = threadIdx.x; i < (IN_E + M1_E + M2_E) / 2; i += 256) reinterpret_cast<u32x4*>(in_map)[i] = u32x4{0, 0, 0, 0};
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * (C / 4); i += 256) stage_tokens(in_map, feat, b, i);
+    __syncthreads();
+    c2.prefetch(tw3 + O3_W2, wave, lane);      // each layer's first pass is requested a layer early
+    c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
+    c3.prefetch(tw3 + O3_W3, wave, lane);
+    __syncthreads();
+    c2.run(m1, m2, tw3 + O3_W2, tw + vth::O_B2, wave, lane);
+    c4.prefetch(tw3 + O3_W4, wave, lane);
+    __syncthreads();
+    c3.run(m2, m1, tw3 + O3_W3, tw + vth::O_B3, wave, lane);
+    __syncthreads();
+    c4.run(m1, m2, tw3 + O3_W4, tw + vth::O_B4, wave, lane);
+    __syncthreads();
+    if (threadIdx.x < 64) {      // 1x1 conv + activation (head.py:187,194,200-201)
+        const int pix = threadIdx.x, e = G::interior(pix >> 3, pix & 7);
+        const f4 v = join3(m2[e], m2[G::NPIX + e], m2[2 * G::NPIX + e]);
+        const int nout = (t == 0) ? 1 : 2;
+        for (int o = 0; o < nout; ++o) {
+            const f4 w5 = ld4(tw + vth::O_W5 + 4 * o);
+            float y = tw[vth::O_B5 + o];
+            y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
+            if (t == 0) score[(size_t)b * 64 + pix] = sigmoid_clamped(y);
+            else if (t == 2) size[((size_t)b * 2 + o) * 64 + pix] = sigmoid_clamped(y);
+            else offset[((size_t)b * 2 + o) * 64 + pix] = y;
+        }
+    }
+}
+
+// One workgroup of 12 waves per frame: the three towers + both decodes (the structure of vth::head_fused_kernel<8>).
+__global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                          const u32x4* __restrict__ hw3, const float* __restrict__ window,
+                                                          float* __restrict__ score, float* __restrict__ size,
+                                                          float* __restrict__ offset, float* __restrict__ pred,
+                                                          float* __restrict__ hann, float* __restrict__ conf) {
+    constexpr int F = 8;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    u32x2* in_map = reinterpret_cast<u32x2*>(sm);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = wave >> 2, wv = wave & 3, tid = threadIdx.x - 256 * t;
+    u32x2* m1 = in_map + IN_E + t * (M1_E + M2_E);
+    u32x2* m2 = m1 + M1_E;
+    float* outs = reinterpret_cast<float*>(in_map + IN_E + 3 * (M1_E + M2_E));     // [5][64]
+    const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
+    const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
+    HeadConv3<C, W1> c1;
+    HeadConv3<W1, 16> c2;
+    HeadConv3<16, 8> c3;
+    HeadConv3<8, 4> c4;
+    c1.prefetch(tw3 + O3_W1, wv, lane);        // flies during the map set-up
+    static_assert(64 * (C / 4) == 768, "one staged element per thread");
+    const f4 fv = ld4(feat + ((size_t)b * 64 + (threadIdx.x & 63)) * C + 4 * (threadIdx.x >> 6));     // requested before the LDS is cleared
+    float win = 0.f;
+    if (wave == 0 && window != nullptr) win = window[lane];
+    for (int i = threadIdx.x; i < (IN_E + 3 * (M1_E + M2_E)) / 2; i += 768) reinterpret_cast<u32x4*>(in_map)[i] = u32x4{0, 0, 0, 0};
+    __syncthreads();
+    {
+        const int icq = threadIdx.x >> 6, pix = threadIdx.x & 63;
+        u32x2 h, m, l;
+        split3(fv, h, m, l);
+        const int e = icq * G::NPIX + G::interior(pix >> 3, pix & 7);
+        in_map[e] = h; in_map[(C / 4) * G::NPIX + e] = m; in_map[2 * (C / 4) * G::NPIX + e] = l;
+    }
+    __syncthreads();
+    c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wv, lane);
+    __syncthreads();
+    const int slot = wv;
+    c2.template run<true>(m1, m2, tw3 + O3_W2, tw + vth::O_B2, slot, lane);
+    __syncthreads();
+    c3.template run<true>(m2, m1, tw3 + O3_W3, tw + vth::O_B3, slot, lane);
+    __syncthreads();
+    c4.template run<true>(m1, m2, tw3 + O3_W4, tw + vth::O_B4, slot, lane);
+    __syncthreads();
+    if (tid < F * F) {
+        const int pix = tid, e = G::interior(pix >> 3, pix & 7);
+        const f4 v = join3(m2[e], m2[G::NPIX + e], m2[2 * G::NPIX + e]);
+        const int nout = (t == 0) ? 1 : 2;
+        for (int o = 0; o < nout; ++o) {
+            const f4 w5 = ld4(tw + vth::O_W5 + 4 * o);
+            float y = tw[vth::O_B5 + o];
+            y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
+            if (t == 0) { y = sigmoid_clamped(y); score[(size_t)b * F * F + pix] = y; outs[pix] = y; }
+            else if (t == 2) { y = sigmoid_clamped(y); size[((size_t)b * 2 + o) * F * F + pix] = y; outs[(1 + o) * F * F + pix] = y; }
+            else { offset[((size_t)b * 2 + o) * F * F + pix] = y; outs[(3 + o) * F * F + pix] = y; }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {      // cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105)
+        const float sc = outs[lane];
+        float v0 = sc, v1 = window != nullptr ? win * sc : -3.0e38f;
+        int i0 = lane, i1 = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            vth::argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
+            vth::argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
+        }
+        if (lane == 0) {
+            constexpr int n = F * F;
+            const float fF = (float)F;
+            const float* sz = outs + n;
+            const float* of = outs + 3 * n;
+            if (pred != nullptr) {
+                pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
+                pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
+                pred[b * 4 + 2] = sz[i0];
+                pred[b * 4 + 3] = sz[n + i0];
+            }
+            if (hann != nullptr && window != nullptr) {
+                hann[b * 4 + 0] = ((float)(i1 % F) + of[i1]) / fF;
+                hann[b * 4 + 1] = ((float)(i1 / F) + of[n + i1]) / fF;
+                hann[b * 4 + 2] = sz[i1];
+                hann[b * 4 + 3] = sz[n + i1];
+            }
+            if (conf != nullptr) conf[b] = v0;
+        }
+    }
+}
+
+}  // namespace vth3
+#endif  // !VT_F16

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
         if (!(skip & 4)) {
             if (do_x) {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
-                constexpr int P2 = G::TX / 4 + 1, H2 = G::TX / 8, P3 = G::TX / 8 + 1, H3 = G::TX / 16;
+                constexpr int P2 = G::TX / 4 + 1, P3 = G::TX / 8 + 1, H3 = G::TX / 16;
                 int base[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) base[i] = 2 * ((wave >> 1) + 8 * i) * P2 + px;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                 }
             }
             if (wave < 8 && do_z) {   // template: 4 pixel tiles of the 8 x 8 map
-                constexpr int P2 = G::TZ / 4 + 1, H2 = G::TZ / 8, P3 = G::TZ / 8 + 1, H3 = G::TZ / 16;
+                constexpr int P2 = G::TZ / 4 + 1, P3 = G::TZ / 8 + 1, H3 = G::TZ / 16;
                 const int op = 16 * (wave >> 1) + px, y = op >> 3, x = op & 7;
                 int base[1] = {2 * y * P2 + x};
                 f4 acc[1][1] = {{bv3}};
@@ -455,8 +455,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         const bool is_z = z4;
         const int tile = tile4, ot = ot4;
         const int lgS4 = is_z ? 2 : 3;
-        const int P3 = is_z ? G::TZ / 8 + 1 : G::TX / 8 + 1, H3 = is_z ? G::TZ / 16 : G::TX / 16;
-        const int npix3 = is_z ? G::NPIX3Z : G::NPIX3X;
+        const int P3 = is_z ? G::TZ / 8 + 1 : G::TX / 8 + 1;
         const f4* map3 = is_z ? m3z : m3x;
         const int op = 16 * tile + px, y = op >> lgS4, x = op & ((1 << lgS4) - 1);
         int base[1] = {2 * y * P3 + x};
