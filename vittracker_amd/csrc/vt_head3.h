@@ -178,12 +178,103 @@ struct HeadConv3 {
             }
         }
     }
+    // ---- the same layer with its weights shared by the tower's four waves through LDS (1-output-tile layers, one pixel tile per
+    // wave): every wave of a tower needs the WHOLE image, so streamed per wave it crosses the L2 -> CU path four times.  The image
+    // moves in staged passes of <= SP chunk pairs: while pass p is computed from one staging buffer the tower's 256 threads fetch
+    // pass p + 1 (or the next layer's first pass) and park it in the other; one workgroup barrier per pass, which is also the
+    // layer's barrier after the last pass.  g = running pass count over the layers (buffer = g & 1).
+    static constexpr int SP = 3, NSP = (NCP + SP - 1) / SP, SBUF16 = SP * 192;       // staging buffer: 9 KiB
+    struct Stager {
+        u32x4 r[3];
+        __device__ __forceinline__ void load(const u32x4* __restrict__ src, int n16, int tid) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (tid + 256 * j < n16) r[j] = src[tid + 256 * j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __device__ __forceinline__ void store(u32x4* dst, int n16, int tid) const {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (tid + 256 * j < n16) dst[tid + 256 * j] = r[j];
+        }
+    };
+    static constexpr int pass_n16(int p) { return (p + 1 < NSP ? SP : NCP - (NSP - 1) * SP) * 192; }
+    __device__ __forceinline__ void run_staged(const u32x2* in_map, u32x2* out_map, const u32x4* __restrict__ wimg,
+                                               const float* __restrict__ bias, int wave, int lane, int tid, u32x4* buf0, u32x4* buf1,
+                                               int g0, const u32x4* __restrict__ next_img, int next_n16) {
+        static_assert(NOT == 1 && NPT == 1 && ACT == NW, "staged form: one output tile, one pixel tile per wave");
+        const int q = lane >> 4;
+        f4 acc = ld4(bias + 4 * q);
+        int cb[3];
+        G::tap_cols(wave, lane, cb);
+        const int centre = cb[1] + G::P;
+        auto at = [&](int c) {
+            int tap, icq;
+            if constexpr (NQ % 4 == 0) { const int cc = c < NCH ? c : NCH - 1; tap = (4 * cc) / NQ; icq = 4 * cc - tap * NQ + q; }
+            else vtc::decode_quad<NQ>(4 * c + q, tap, icq);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            return icq * G::NPIX + dy * G::P + (dx == 0 ? cb[0] : (dx == 1 ? cb[1] : cb[2]));
+        };
+        auto read_b = [&](int cp, u32x4 (&b)[3]) {
+            const int o0 = at(2 * cp), o1 = at(2 * cp + 1);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const u32x2 lo = in_map[pc * PS_IN + o0], hi = in_map[pc * PS_IN + o1];
+                b[pc] = u32x4{lo.x, lo.y, hi.x, hi.y};
+            }
+        };
+        Stager st;
+        u32x4 b[2][3];
+        read_b(0, b[0]);
+#pragma unroll
+        for (int p = 0; p < NSP; ++p) {
+            const int n = pass_n16(p) / 192;
+            if (p + 1 < NSP) st.load(wimg + (size_t)(p + 1) * SBUF16, pass_n16(p + 1), tid);
+            else if (next_img != nullptr) st.load(next_img, next_n16, tid);
+            const u32x4* sb = ((g0 + p) & 1) ? buf1 : buf0;
+            u32x4 w[SP][3];
+#pragma unroll
+            for (int k = 0; k < SP; ++k)
+                if (k < n)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) w[k][pc] = sb[(k * 3 + pc) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < SP; ++k) {
+                if (k >= n) break;
+                const int cp = p * SP + k;
+                if (cp + 1 < NCP) {
+                    read_b(cp + 1, b[(cp + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 (&x)[3] = b[cp & 1];
+                auto mm = [&](int wp, int xp) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[k][wp]), __builtin_bit_cast(bf16x8, x[xp]), acc, 0, 0, 0);
+                };
+                mm(2, 0); mm(0, 2); mm(1, 1); mm(1, 0); mm(0, 1); mm(0, 0);
+            }
+            if (p == NSP - 1 && 4 * q < COUT) {
+                f4 v = acc;
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                u32x2 h, m, l;
+                split3(v, h, m, l);
+                const int e = q * G::NPIX + centre;
+                out_map[e] = h; out_map[PS_OUT + e] = m; out_map[2 * PS_OUT + e] = l;
+            }
+            u32x4* db = ((g0 + p + 1) & 1) ? buf1 : buf0;
+            if (p + 1 < NSP) st.store(db, pass_n16(p + 1), tid);
+            else if (next_img != nullptr) st.store(db, next_n16, tid);
+            __syncthreads();
+        }
+    }
 };
 
 // LDS entries (uint2) of the maps: input 3 x 12 planes, per tower m1 3 x 8 and m2 3 x 4 planes
 constexpr int IN_E = 3 * (C / 4) * G::NPIX, M1_E = 3 * (W1 / 4) * G::NPIX, M2_E = 3 * 4 * G::NPIX;
 constexpr int TOWERS3_LDS_BYTES = (IN_E + M1_E + M2_E) * 8;
-constexpr int FUSED3_LDS_BYTES = (IN_E + 3 * (M1_E + M2_E)) * 8 + 5 * 64 * 4;
+constexpr int SBUF_BYTES = 3 * 192 * 16;                        // one staged pass of weights (HeadConv3::run_staged): 9 KiB
+static_assert(IN_E * 8 / 3 >= SBUF_BYTES, "a tower's second staging buffer is its third of the input map (dead after conv1)");
+constexpr int FUSED3_LDS_BYTES = (IN_E + 3 * (M1_E + M2_E)) * 8 + 5 * 64 * 4 + 3 * SBUF_BYTES;
+static_assert(FUSED3_LDS_BYTES <= 160 * 1024, "LDS");
 
 // tokens (B,HW,C) fp32 -> the piece planes of the input map (vit_dist.py:126-129): item = (quad, pixel)
 __device__ __forceinline__ void stage_tokens(u32x2* in_map, const float* __restrict__ feat, int b, int item) {
@@ -279,15 +370,19 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
         in_map[e] = h; in_map[(C / 4) * G::NPIX + e] = m; in_map[2 * (C / 4) * G::NPIX + e] = l;
     }
     __syncthreads();
+    // conv2-4: weights through the tower's two LDS staging buffers (run_staged): buffer 0 behind the output rows, buffer 1 the
+    // tower's third of the input map once conv1 is done with it.  conv2's first pass is fetched before conv1 and parked after it.
+    u32x4* const sbuf0 = reinterpret_cast<u32x4*>(outs + 5 * 64) + t * (SBUF_BYTES / 16);
+    u32x4* const sbuf1 = reinterpret_cast<u32x4*>(in_map) + t * (IN_E / 6);          // IN_E / 3 entries of 8 bytes = IN_E / 6 x 16 bytes
+    HeadConv3<W1, 16>::Stager st0;
+    st0.load(tw3 + O3_W2, HeadConv3<W1, 16>::pass_n16(0), tid);
     c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wv, lane);
+    st0.store(sbuf0, HeadConv3<W1, 16>::pass_n16(0), tid);
     __syncthreads();
-    const int slot = wv;
-    c2.template run<true>(m1, m2, tw3 + O3_W2, tw + vth::O_B2, slot, lane);
-    __syncthreads();
-    c3.template run<true>(m2, m1, tw3 + O3_W3, tw + vth::O_B3, slot, lane);
-    __syncthreads();
-    c4.template run<true>(m1, m2, tw3 + O3_W4, tw + vth::O_B4, slot, lane);
-    __syncthreads();
+    constexpr int G3 = HeadConv3<W1, 16>::NSP, G4 = G3 + HeadConv3<16, 8>::NSP;
+    c2.run_staged(m1, m2, tw3 + O3_W2, tw + vth::O_B2, wv, lane, tid, sbuf0, sbuf1, 0, tw3 + O3_W3, HeadConv3<16, 8>::pass_n16(0));
+    c3.run_staged(m2, m1, tw3 + O3_W3, tw + vth::O_B3, wv, lane, tid, sbuf0, sbuf1, G3, tw3 + O3_W4, HeadConv3<8, 4>::pass_n16(0));
+    c4.run_staged(m1, m2, tw3 + O3_W4, tw + vth::O_B4, wv, lane, tid, sbuf0, sbuf1, G4, nullptr, 0);
     if (tid < F * F) {
         const int pix = tid, e = G::interior(pix >> 3, pix & 7);
         const f4 v = join3(m2[e], m2[G::NPIX + e], m2[2 * G::NPIX + e]);
