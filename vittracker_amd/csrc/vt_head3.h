@@ -22,6 +22,9 @@
 #include "vt_head.h"
 
 #ifndef VT_F16
+#ifndef VT_H3_SKIP
+#define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs, 4 = no weight loads in conv1
+#endif
 namespace vth3 {
 
 using vth::C;
@@ -78,14 +81,14 @@ __device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {
 // weight image from L2, and with the MFMAs 2.6 x cheaper that stream -- not the matrix pipe -- bounds the towers (1.1 MB per frame
 // with four waves per layer against 405 KB of distinct weights, at ~72 GB/s per CU); two waves with two pixel tiles each halve
 // it for conv2-4 but double those waves' chains: measured 17.3 against 16.6 us, so all four work.
-template <int CIN, int COUT, int NW = 4, int ACT = NW>
+template <int CIN, int COUT, int NW = 4, int ACT = NW, int MAXP_ = 2>
 struct HeadConv3 {
     static constexpr int NQ = CIN / 4, NQO = COUT / 4, NCH = nchunks(CIN), NCP = npairs(CIN), NOT = ntiles(COUT);
     static constexpr bool SPLIT_OT = NOT == 2;
     static constexpr int TSTEP = SPLIT_OT ? NW / 2 : ACT;
     static constexpr int NPT = G::NT / TSTEP;
     static_assert(G::NT % TSTEP == 0 && NPT >= 1 && NOT <= 2, "work split");
-    static constexpr int MAXP = NCP < 2 ? NCP : 2;      // 2 pairs x 3 pieces x 4 registers, double-buffered = 48 registers (768 threads: 168 per lane)
+    static constexpr int MAXP = NCP < MAXP_ ? NCP : MAXP_;      // pairs per register pass: 2 x 3 pieces x 4 registers, double-buffered = 48 registers (768 threads: 168 per lane)
     static constexpr int NPASS = (NCP + MAXP - 1) / MAXP;
     static constexpr int PS_IN = NQ * G::NPIX, PS_OUT = NQO * G::NPIX;       // piece strides (entries)
     u32x4 a[2][MAXP][3];
@@ -179,29 +182,16 @@ struct HeadConv3 {
         }
     }
     // ---- the same layer with its weights shared by the tower's four waves through LDS (1-output-tile layers, one pixel tile per
-    // wave): every wave of a tower needs the WHOLE image, so streamed per wave it crosses the L2 -> CU path four times.  The image
-    // moves in staged passes of <= SP chunk pairs: while pass p is computed from one staging buffer the tower's 256 threads fetch
-    // pass p + 1 (or the next layer's first pass) and park it in the other; one workgroup barrier per pass, which is also the
-    // layer's barrier after the last pass.  g = running pass count over the layers (buffer = g & 1).
+    // wave): every wave of a tower needs the WHOLE image, so streamed per wave it crosses the L2 -> CU path four times.  The images
+    // of conv2-4 move as one sequence of staged passes of <= SP chunk pairs (WeightPipe below): pass j is fetched by the tower's 256
+    // threads at the start of pass j - 2, parked in staging buffer j & 1 at the end of pass j - 1 and read by all four waves in
+    // pass j; one workgroup barrier per pass, which is also the layer's barrier after its last pass.  (Fetched only one pass ahead
+    // every pass waited for its own L2 round trip: 6 passes x ~1 us.)
     static constexpr int SP = 3, NSP = (NCP + SP - 1) / SP, SBUF16 = SP * 192;       // staging buffer: 9 KiB
-    struct Stager {
-        u32x4 r[3];
-        __device__ __forceinline__ void load(const u32x4* __restrict__ src, int n16, int tid) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (tid + 256 * j < n16) r[j] = src[tid + 256 * j];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __device__ __forceinline__ void store(u32x4* dst, int n16, int tid) const {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                if (tid + 256 * j < n16) dst[tid + 256 * j] = r[j];
-        }
-    };
     static constexpr int pass_n16(int p) { return (p + 1 < NSP ? SP : NCP - (NSP - 1) * SP) * 192; }
-    __device__ __forceinline__ void run_staged(const u32x2* in_map, u32x2* out_map, const u32x4* __restrict__ wimg,
-                                               const float* __restrict__ bias, int wave, int lane, int tid, u32x4* buf0, u32x4* buf1,
-                                               int g0, const u32x4* __restrict__ next_img, int next_n16) {
+    template <typename Pipe>
+    __device__ __forceinline__ void run_staged(const u32x2* in_map, u32x2* out_map, const float* __restrict__ bias, int wave, int lane,
+                                               int g0, Pipe& pipe) {
         static_assert(NOT == 1 && NPT == 1 && ACT == NW, "staged form: one output tile, one pixel tile per wave");
         const int q = lane >> 4;
         f4 acc = ld4(bias + 4 * q);
@@ -223,34 +213,31 @@ struct HeadConv3 {
                 b[pc] = u32x4{lo.x, lo.y, hi.x, hi.y};
             }
         };
-        Stager st;
-        u32x4 b[2][3];
+        u32x4 b[2][3], w[2][3];
         read_b(0, b[0]);
 #pragma unroll
         for (int p = 0; p < NSP; ++p) {
-            const int n = pass_n16(p) / 192;
-            if (p + 1 < NSP) st.load(wimg + (size_t)(p + 1) * SBUF16, pass_n16(p + 1), tid);
-            else if (next_img != nullptr) st.load(next_img, next_n16, tid);
-            const u32x4* sb = ((g0 + p) & 1) ? buf1 : buf0;
-            u32x4 w[SP][3];
+            const int n = pass_n16(p) / 192, g = g0 + p;
+            pipe.fetch(g + 2);
+            const u32x4* sb = pipe.buf(g);
+            auto read_w = [&](int k, u32x4 (&ww)[3]) {
 #pragma unroll
-            for (int k = 0; k < SP; ++k)
-                if (k < n)
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) w[k][pc] = sb[(k * 3 + pc) * 64 + lane];
+                for (int pc = 0; pc < 3; ++pc) ww[pc] = sb[(k * 3 + pc) * 64 + lane];
+            };
+            read_w(0, w[0]);
 #pragma unroll
             for (int k = 0; k < SP; ++k) {
                 if (k >= n) break;
                 const int cp = p * SP + k;
-                if (cp + 1 < NCP) {
-                    read_b(cp + 1, b[(cp + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if (k + 1 < n) read_w(k + 1, w[(k + 1) & 1]);
+                if (cp + 1 < NCP) read_b(cp + 1, b[(cp + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
                 const u32x4 (&x)[3] = b[cp & 1];
+                const u32x4 (&ww)[3] = w[k & 1];
                 auto mm = [&](int wp, int xp) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[k][wp]), __builtin_bit_cast(bf16x8, x[xp]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ww[wp]), __builtin_bit_cast(bf16x8, x[xp]), acc, 0, 0, 0);
                 };
-                mm(2, 0); mm(0, 2); mm(1, 1); mm(1, 0); mm(0, 1); mm(0, 0);
+                if (!(VT_H3_SKIP & 2)) { mm(2, 0); mm(0, 2); mm(1, 1); mm(1, 0); mm(0, 1); mm(0, 0); }
             }
             if (p == NSP - 1 && 4 * q < COUT) {
                 f4 v = acc;
@@ -260,9 +247,7 @@ struct HeadConv3 {
                 const int e = q * G::NPIX + centre;
                 out_map[e] = h; out_map[PS_OUT + e] = m; out_map[2 * PS_OUT + e] = l;
             }
-            u32x4* db = ((g0 + p + 1) & 1) ? buf1 : buf0;
-            if (p + 1 < NSP) st.store(db, pass_n16(p + 1), tid);
-            else if (next_img != nullptr) st.store(db, next_n16, tid);
+            pipe.park(g + 1);
             __syncthreads();
         }
     }
@@ -275,6 +260,38 @@ constexpr int SBUF_BYTES = 3 * 192 * 16;                        // one staged pa
 static_assert(IN_E * 8 / 3 >= SBUF_BYTES, "a tower's second staging buffer is its third of the input map (dead after conv1)");
 constexpr int FUSED3_LDS_BYTES = (IN_E + 3 * (M1_E + M2_E)) * 8 + 5 * 64 * 4 + 3 * SBUF_BYTES;
 static_assert(FUSED3_LDS_BYTES <= 160 * 1024, "LDS");
+
+// The staged passes of conv2, conv3, conv4 of one tower, in order (3 + 2 + 1 passes), two register slots and two LDS buffers.
+struct WeightPipe {
+    static constexpr int N2 = HeadConv3<W1, 16>::NSP, N3 = HeadConv3<16, 8>::NSP, N4 = HeadConv3<8, 4>::NSP, NP = N2 + N3 + N4;
+    const u32x4* tw3;
+    u32x4 *buf0, *buf1;
+    int tid;
+    u32x4 r[2][3];
+    // 16-byte offset (inside the tower's images) and size of global pass j
+    static constexpr int off16(int j) {
+        return j < N2 ? O3_W2 + j * HeadConv3<W1, 16>::SBUF16 : j < N2 + N3 ? O3_W3 + (j - N2) * HeadConv3<16, 8>::SBUF16 : O3_W4 + (j - N2 - N3) * HeadConv3<8, 4>::SBUF16;
+    }
+    static constexpr int n16(int j) {
+        return j < N2 ? HeadConv3<W1, 16>::pass_n16(j) : j < N2 + N3 ? HeadConv3<16, 8>::pass_n16(j - N2) : HeadConv3<8, 4>::pass_n16(j - N2 - N3);
+    }
+    __device__ __forceinline__ const u32x4* buf(int j) const { return (j & 1) ? buf1 : buf0; }
+    __device__ __forceinline__ void fetch(int j) {           // j compile-time at every call site (the pass loops are unrolled)
+        if (j >= NP) return;
+        const u32x4* __restrict__ src = tw3 + off16(j);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 256 * k < n16(j)) r[j & 1][k] = src[tid + 256 * k];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void park(int j) {
+        if (j >= NP) return;
+        u32x4* dst = (j & 1) ? buf1 : buf0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 256 * k < n16(j)) dst[tid + 256 * k] = r[j & 1][k];
+    }
+};
 
 // tokens (B,HW,C) fp32 -> the piece planes of the input map (vit_dist.py:126-129): item = (quad, pixel)
 __device__ __forceinline__ void stage_tokens(u32x2* in_map, const float* __restrict__ feat, int b, int item) {
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
     float* outs = reinterpret_cast<float*>(in_map + IN_E + 3 * (M1_E + M2_E));     // [5][64]
     const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
     const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
-    HeadConv3<C, W1> c1;
+    HeadConv3<C, W1, 4, 4, 1> c1;          // one pair per register pass: the staged layers' two fetch slots are live across conv1
     HeadConv3<W1, 16> c2;
     HeadConv3<16, 8> c3;
     HeadConv3<8, 4> c4;
@@ -374,15 +391,15 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
     // tower's third of the input map once conv1 is done with it.  conv2's first pass is fetched before conv1 and parked after it.
     u32x4* const sbuf0 = reinterpret_cast<u32x4*>(outs + 5 * 64) + t * (SBUF_BYTES / 16);
     u32x4* const sbuf1 = reinterpret_cast<u32x4*>(in_map) + t * (IN_E / 6);          // IN_E / 3 entries of 8 bytes = IN_E / 6 x 16 bytes
-    HeadConv3<W1, 16>::Stager st0;
-    st0.load(tw3 + O3_W2, HeadConv3<W1, 16>::pass_n16(0), tid);
-    c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wv, lane);
-    st0.store(sbuf0, HeadConv3<W1, 16>::pass_n16(0), tid);
+    WeightPipe pipe{tw3, sbuf0, sbuf1, tid, {}};
+    pipe.fetch(0);
+    pipe.fetch(1);
+    if (!(VT_H3_SKIP & 1)) c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wv, lane);
+    pipe.park(0);
     __syncthreads();
-    constexpr int G3 = HeadConv3<W1, 16>::NSP, G4 = G3 + HeadConv3<16, 8>::NSP;
-    c2.run_staged(m1, m2, tw3 + O3_W2, tw + vth::O_B2, wv, lane, tid, sbuf0, sbuf1, 0, tw3 + O3_W3, HeadConv3<16, 8>::pass_n16(0));
-    c3.run_staged(m2, m1, tw3 + O3_W3, tw + vth::O_B3, wv, lane, tid, sbuf0, sbuf1, G3, tw3 + O3_W4, HeadConv3<8, 4>::pass_n16(0));
-    c4.run_staged(m1, m2, tw3 + O3_W4, tw + vth::O_B4, wv, lane, tid, sbuf0, sbuf1, G4, nullptr, 0);
+    c2.run_staged(m1, m2, tw + vth::O_B2, wv, lane, 0, pipe);
+    c3.run_staged(m2, m1, tw + vth::O_B3, wv, lane, WeightPipe::N2, pipe);
+    c4.run_staged(m1, m2, tw + vth::O_B4, wv, lane, WeightPipe::N2 + WeightPipe::N3, pipe);
     if (tid < F * F) {
         const int pix = tid, e = G::interior(pix >> 3, pix & 7);
         const f4 v = join3(m2[e], m2[G::NPIX + e], m2[2 * G::NPIX + e]);
