@@ -73,26 +73,52 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     const double scale = (double)crop_sz / (double)T;
     int sy0, sy1, by0, by1;
     lin_coeff(oy, crop_sz, scale, sy0, sy1, by0, by1);
-    const unsigned char* fr = frames + (size_t)b * H * W * 3;
+    // Source pixels: an RGB pixel is 3 consecutive bytes, and the two columns a bilinear sample reads are neighbours (or the same
+    // pixel at the crop's edge), so ONE 8-byte load at byte offset 3 x covers both -- 8 loads per thread instead of 48 single-byte
+    // loads, which were the kernel's cost (3072 vector-memory instructions per 128 x 128 crop: 33 us at batch 256, a quarter of the
+    // tracker step).  Buffer loads at byte-unaligned offsets (tools/src/probe_unaligned.hip: the hardware returns the right bytes;
+    // a load that crosses the end of the buffer returns zeros, so the frame's last pixels are read 8 bytes back and shifted).
+    const size_t frame_bytes = (size_t)H * W * 3, rest = (size_t)(gridDim.y - b) * frame_bytes;      // bytes from this frame to the end of the batch
+    const unsigned nrec = rest > 0xfffffff0ull ? 0xfffffff0u : (unsigned)rest;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames + (size_t)b * frame_bytes), 0, (int)nrec, 0x00020000);
     const int yy0 = y1 + sy0, yy1 = y1 + sy1;
     const bool vr0 = yy0 >= vy0 && yy0 < vy1, vr1 = yy1 >= vy0 && yy1 < vy1;
-    const unsigned char* row0 = fr + (size_t)(vr0 ? yy0 : 0) * W * 3;
-    const unsigned char* row1 = fr + (size_t)(vr1 ? yy1 : 0) * W * 3;
+    const unsigned rowo0 = (unsigned)(vr0 ? yy0 : 0) * (unsigned)(W * 3), rowo1 = (unsigned)(vr1 ? yy1 : 0) * (unsigned)(W * 3);
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    auto load8 = [&](unsigned off) -> unsigned long long {      // bytes off .. off + 7 of the frame (the last bytes of the batch: shifted in)
+        const unsigned over = off + 8u > nrec ? off + 8u - nrec : 0u;
+        const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off - over), 0, 0);
+        return (((unsigned long long)v.y << 32) | v.x) >> (8u * over);
+    };
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
     float res[3][4];
+    unsigned long long q0[4], q1[4];
+    int ax0a[4], ax1a[4], sh1[4];
+    bool vc0a[4], vc1a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {       // all eight loads first
+        const int ox = ox0 + k < T ? ox0 + k : T - 1;
+        int sx0, sx1;
+        lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0a[k], ax1a[k]);
+        const int xx0 = x1 + sx0, xx1 = x1 + sx1;
+        vc0a[k] = xx0 >= vx0 && xx0 < vx1; vc1a[k] = xx1 >= vx0 && xx1 < vx1;
+        // base pixel of the 8-byte window: the left column when it is inside the frame, else the right one (then the left is padding)
+        const int xb = vc0a[k] ? xx0 : (vc1a[k] ? xx1 : 0);
+        sh1[k] = vc1a[k] ? 24 * (xx1 - xb) : 0;                     // bit offset of the right column's pixel inside the window: 0 or 24
+        q0[k] = load8(rowo0 + 3u * (unsigned)xb);
+        q1[k] = load8(rowo1 + 3u * (unsigned)xb);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int ox = ox0 + k < T ? ox0 + k : T - 1;
-        int sx0, sx1, ax0, ax1;
-        lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0, ax1);
-        const int xx0 = x1 + sx0, xx1 = x1 + sx1;
-        const bool vc0 = xx0 >= vx0 && xx0 < vx1, vc1 = xx1 >= vx0 && xx1 < vx1;
-        const int o0 = (vc0 ? xx0 : 0) * 3, o1 = (vc1 ? xx1 : 0) * 3;
+        const int ax0 = ax0a[k], ax1 = ax1a[k];
+        const bool vc0 = vc0a[k], vc1 = vc1a[k];
+        // the left column is at bit 0 of the window when it is valid (it is the base); the right one at sh1 (0 when it is the base itself)
+        const unsigned l0 = (unsigned)q0[k], l1 = (unsigned)q1[k], r0w = (unsigned)(q0[k] >> sh1[k]), r1w = (unsigned)(q1[k] >> sh1[k]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             // pixel (cy, cx) of the zero-padded crop: the frame inside the valid range, 0 outside
-            const int p00 = vr0 && vc0 ? (int)row0[o0 + c] : 0, p01 = vr0 && vc1 ? (int)row0[o1 + c] : 0;
-            const int p10 = vr1 && vc0 ? (int)row1[o0 + c] : 0, p11 = vr1 && vc1 ? (int)row1[o1 + c] : 0;
+            const int p00 = vr0 && vc0 ? (int)((l0 >> (8 * c)) & 0xffu) : 0, p01 = vr0 && vc1 ? (int)((r0w >> (8 * c)) & 0xffu) : 0;
+            const int p10 = vr1 && vc0 ? (int)((l1 >> (8 * c)) & 0xffu) : 0, p11 = vr1 && vc1 ? (int)((r1w >> (8 * c)) & 0xffu) : 0;
             const int r0 = p00 * ax0 + p01 * ax1;
             const int r1 = p10 * ax0 + p11 * ax1;
             int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
