@@ -43,6 +43,27 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
                                                    float m0, float m1, float m2, float s0, float s1, float s2,
                                                    float* __restrict__ out, double* __restrict__ resize_factor) {
     const int b = blockIdx.y;
+    // Preprocessor.process maps a uint8 value to (v / 255 - mean) / std: 256 x 3 possible results.  They are computed ONCE per
+    // workgroup with the reference's arithmetic (three separately rounded fp32 ops, below) into an LDS table -- per output value
+    // one LDS read instead of a convert, a multiply, a subtract and an IEEE division sequence (~14 VALU instructions of the ~74 a
+    // value cost).
+    __shared__ float norm_lut[3 * 256];
+    {
+        const float meanv[3] = {m0, m1, m2}, stdq[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // torch's CUDA `tensor / 255.0` multiplies by the float reciprocal (div_true with a CPU scalar);
+            // Preprocessor.process runs on the GPU, so that is the reference arithmetic
+            // Three separately rounded ops, as three torch kernels: the empty asm keeps hipcc from
+            // contracting the multiply and the subtraction into one fma (the _rn intrinsics do not).
+            float scaled = (float)(int)threadIdx.x * (1.0f / 255.0f);
+            asm volatile("" : "+v"(scaled));
+            float centred = scaled - meanv[c];
+            asm volatile("" : "+v"(centred));
+            norm_lut[c * 256 + threadIdx.x] = centred / stdq[c];
+        }
+    }
+    __syncthreads();
     const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
     const int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
     const int T4 = (T + 3) >> 2;                      // pixel groups per row
@@ -90,7 +111,6 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
         const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off - over), 0, 0);
         return (((unsigned long long)v.y << 32) | v.x) >> (8u * over);
     };
-    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
     float res[3][4];
     unsigned long long q0[4], q1[4];
     int ax0a[4], ax1a[4], sh1[4];
@@ -113,25 +133,19 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
         const int ax0 = ax0a[k], ax1 = ax1a[k];
         const bool vc0 = vc0a[k], vc1 = vc1a[k];
         // the left column is at bit 0 of the window when it is valid (it is the base); the right one at sh1 (0 when it is the base itself)
-        const unsigned l0 = (unsigned)q0[k], l1 = (unsigned)q1[k], r0w = (unsigned)(q0[k] >> sh1[k]), r1w = (unsigned)(q1[k] >> sh1[k]);
+        // pixel (cy, cx) of the zero-padded crop: the frame inside the valid range, 0 outside (masked once per pixel, all channels)
+        const unsigned l0 = vr0 && vc0 ? (unsigned)q0[k] : 0u, l1 = vr1 && vc0 ? (unsigned)q1[k] : 0u;
+        const unsigned r0w = vr0 && vc1 ? (unsigned)(q0[k] >> sh1[k]) : 0u, r1w = vr1 && vc1 ? (unsigned)(q1[k] >> sh1[k]) : 0u;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            // pixel (cy, cx) of the zero-padded crop: the frame inside the valid range, 0 outside
-            const int p00 = vr0 && vc0 ? (int)((l0 >> (8 * c)) & 0xffu) : 0, p01 = vr0 && vc1 ? (int)((r0w >> (8 * c)) & 0xffu) : 0;
-            const int p10 = vr1 && vc0 ? (int)((l1 >> (8 * c)) & 0xffu) : 0, p11 = vr1 && vc1 ? (int)((r1w >> (8 * c)) & 0xffu) : 0;
-            const int r0 = p00 * ax0 + p01 * ax1;
-            const int r1 = p10 * ax0 + p11 * ax1;
-            int v = (((by0 * (r0 >> 4)) >> 16) + ((by1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            const int p00 = (int)((l0 >> (8 * c)) & 0xffu), p01 = (int)((r0w >> (8 * c)) & 0xffu);
+            const int p10 = (int)((l1 >> (8 * c)) & 0xffu), p11 = (int)((r1w >> (8 * c)) & 0xffu);
+            // every factor is below 2^24 (8-bit pixels, 12-bit weights, 15-bit row sums): the 24-bit multiplier gives the same integers
+            const int r0 = __mul24(p00, ax0) + __mul24(p01, ax1);
+            const int r1 = __mul24(p10, ax0) + __mul24(p11, ax1);
+            int v = ((__mul24(by0, r0 >> 4) >> 16) + (__mul24(by1, r1 >> 4) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            // torch's CUDA `tensor / 255.0` multiplies by the float reciprocal (div_true with a CPU scalar);
-            // Preprocessor.process runs on the GPU, so that is the reference arithmetic
-            // Three separately rounded ops, as three torch kernels: the empty asm keeps hipcc from
-            // contracting the multiply and the subtraction into one fma (the _rn intrinsics do not).
-            float scaled = (float)v * (1.0f / 255.0f);
-            asm volatile("" : "+v"(scaled));
-            float centred = scaled - mean[c];
-            asm volatile("" : "+v"(centred));
-            res[c][k] = centred / stdv[c];
+            res[c][k] = norm_lut[c * 256 + v];
         }
     }
 #pragma unroll
