@@ -524,12 +524,12 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         // towers + both decodes in one workgroup per frame
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
-                               size, offset, pred, hann, conf, m->skip_head);
+                               size, offset, pred, hann, conf, m->skip_head, tail ? *tail : TrackTail{}, tail ? 1 : 0);
         };
         if (m->skip_head) go(&vth::head_fused_kernel<8, true>);
         else go(&vth::head_fused_kernel<8, false>);
         HIP_TRY(hipGetLastError());
-        return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
+        return VT_OK;       // (the tracker's tail, if any, ran on the kernel's decoding lane)
     }
     if (m->F == 8) {
         if (m->skip_head)
@@ -542,12 +542,12 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         // one workgroup per frame: the three towers in turn on one staged input map, decode from LDS (no decode launch)
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(512), vth::SeqHeadGeo<16>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
-                               size, offset, pred, hann, conf, m->skip_head);
+                               size, offset, pred, hann, conf, m->skip_head, tail ? *tail : TrackTail{}, tail ? 1 : 0);
         };
         if (m->skip_head) go(&vth::head_seq_kernel<16, 8, true>);
         else go(&vth::head_seq_kernel<16, 8, false>);
         HIP_TRY(hipGetLastError());
-        return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
+        return VT_OK;       // (tail: on the kernel's decoding lane)
     } else if (m->F == 16 && !m->skip_head && B <= m->head_m1_frames && f0 == 0 &&
                (m->head_split < 0 ? B <= HEAD_SPLIT_MAX_B : m->head_split != 0)) {
         // small batches: conv1 of every tower over four row strips (12 workgroups per frame), then the rest of each tower
