@@ -50,6 +50,26 @@ def test_device_crop_equals_host_crop(T, factor):
         np.testing.assert_array_equal(crops[b], want, err_msg=f"box {boxes[b]}")
 
 
+def test_device_crop_random_boxes_on_odd_frame_sizes():
+    """The crop kernel reads a sample's two source columns as one unaligned 8-byte load: random boxes (inside, across borders, at the
+    corners, at the very end of the batch's memory) on frames whose row length is not a multiple of anything."""
+    import torch
+    rs = np.random.RandomState(11)
+    H, W, T = 37, 53, 64
+    boxes = [[rs.uniform(-10, W), rs.uniform(-10, H), rs.uniform(2, 40), rs.uniform(2, 40)] for _ in range(45)]
+    boxes += [[W - 6, H - 5, 6, 5], [W - 3.5, H - 3.5, 3, 3], [0, 0, W, H], [W - 1, H - 1, 1, 1], [W - 12, H - 9, 12.5, 9.5]]
+    B = len(boxes)
+    frames = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    m = _nat(B=B)
+    for factor in (2.0, 4.0):
+        crops, rf = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), factor, T, MEAN, STD)
+        crops, rf = crops.cpu().numpy(), rf.cpu().numpy()
+        for b in range(B):
+            want, want_rf = _host_crop(frames[b], boxes[b], factor, T)
+            assert rf[b] == want_rf
+            np.testing.assert_array_equal(crops[b], want, err_msg=f"box {boxes[b]} factor {factor}")
+
+
 def test_device_crop_geometry_matches_reference_fixture():
     """vt_crop's crop / pad geometry against the fixtures the REFERENCE's sample_target produced
     (tests/golden/ref_crop_geometry.npz).  With out_size == crop side the fixed-point resize is the
