@@ -48,9 +48,12 @@ VARIANTS = {
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},
     "per_tower_head": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "0"},
-    # the G128 head's towers on the bf16 matrix pipe with exact three-piece operands (vt_head3.h, opt-in), both kernel forms
+    # the G128 head's towers on the bf16 matrix pipe with exact three-piece operands (vt_head3.h; the default), both kernel forms,
+    # and the fp32-MFMA towers they replaced (VT_HEAD_BF3=0; F = 16 always runs those)
     "head_bf16x3_small_batch_form": {"VT_HEAD_BF3": "1"},
     "head_bf16x3_fused_form": {"VT_HEAD_BF3": "1", "VT_HEAD_FUSED": "1"},
+    "head_fp32_mfma_small_batch_form": {"VT_HEAD_BF3": "0"},
+    "head_fp32_mfma_fused_form": {"VT_HEAD_BF3": "0", "VT_HEAD_FUSED": "1"},
     "g256_head_conv1_split_forced": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "1"},
     "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1", "VT_BLOCKS_TILE": "0"},
     "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0", "VT_BLOCKS_TILE": "0"},

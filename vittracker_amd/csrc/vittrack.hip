@@ -72,7 +72,7 @@ struct vt_model {
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
     DevBuf head;                     // 3 * TOWER_STRIDE
     DevBuf head3;                    // F = 8, fp32 build: the towers' weights as three-piece bf16 images (vt_head3.h)
-    int head_bf3 = 0;                // VT_HEAD_BF3: the towers on the bf16 matrix pipe at fp32 accuracy (F = 8); opt-in
+    int head_bf3 = 1;                // VT_HEAD_BF3: the towers on the bf16 matrix pipe at fp32 accuracy (F = 8); 0 = fp32 MFMA towers
     DevBuf window;                   // F*F
     // workspace sized for max_batch
     DevBuf act_x, act_z;             // layer-2 activations, NHWC(12)
@@ -765,7 +765,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
     m->stem_stream = env_int("VT_STEM_STREAM", -1);
     m->head_fused = env_int("VT_HEAD_FUSED", -1);
-    m->head_bf3 = env_int("VT_HEAD_BF3", 0);      // opt-in: under sustained load the chip gives the towers' gain back in clocks
+    m->head_bf3 = env_int("VT_HEAD_BF3", 1);      // default since the sustained A/B (tools/power_probe.py): 93.5 -> 86.4 us per step at equal clocks
     m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
