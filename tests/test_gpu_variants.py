@@ -54,6 +54,8 @@ VARIANTS = {
     "head_bf16x3_fused_form": {"VT_HEAD_BF3": "1", "VT_HEAD_FUSED": "1"},
     "head_fp32_mfma_small_batch_form": {"VT_HEAD_BF3": "0"},
     "head_fp32_mfma_fused_form": {"VT_HEAD_BF3": "0", "VT_HEAD_FUSED": "1"},
+    # the G128 frame form's MLP on fp32 MFMAs (the default multiplies exact three-piece bf16 splits: vt_blocks.h BF3, vt_bf3.h)
+    "blocks_mlp_fp32_mfma": {"VT_BLOCKS_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
     "g256_head_conv1_split_forced": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "1"},
     "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1", "VT_BLOCKS_TILE": "0"},
     "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0", "VT_BLOCKS_TILE": "0"},

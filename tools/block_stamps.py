@@ -29,8 +29,9 @@ if fine and geom == "G128":
                                   f"b{k} fc1 g1+gelu0 (48)", f"b{k} fc1 g2+gelu1 (48)", f"b{k} barrier3", f"b{k} fc2 g0+gelu2 (48)",
                                   f"b{k} fc2 g1 (48)", f"b{k} fc2 g2 (48)"] for k in range(3)], []) + ["barrier4+tail"]
 elif geom == "G128":   # WLDS variant: a barrier splits the MLP
-    names = sum([[f"b{k} (load)ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} ln2+fc1+gelu01",
-                   f"b{k} barrier3", f"b{k} fc2+gelu2", f"b{k} barrier4"] for k in range(3)], []) + ["tail"]
+    # no stamp behind a block's last barrier: a block's first phase includes the previous block's closing barrier (block 0: the load)
+    names = sum([[f"b{k} (load|barrier4)+ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} ln2+fc1+gelu01",
+                   f"b{k} barrier3", f"b{k} fc2+gelu2"] for k in range(3)], []) + ["barrier4+tail"]
 else:
     names = sum([[f"b{k} (load)ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} mlp"] for k in range(3)], []) + ["tail"]
 bal = os.environ.get("VT_BLOCKS_BAL", "1") != "0"

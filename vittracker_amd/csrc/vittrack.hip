@@ -70,6 +70,7 @@ struct vt_model {
     DevBuf stem_w2k;                 // layer 2 again as [tap][input-channel quad][16 output channels][4] for the 4-block f32 MFMA
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
+    DevBuf blocks3;                  // depth * BLOCK3_STRIDE: the MLP's three-piece bf16 images (vt_blocks.h, BF3)
     DevBuf head;                     // 3 * TOWER_STRIDE
     DevBuf head3;                    // F = 8, fp32 build: the towers' weights as three-piece bf16 images (vt_head3.h)
     int head_bf3 = 1;                // VT_HEAD_BF3: the towers on the bf16 matrix pipe at fp32 accuracy (F = 8); 0 = fp32 MFMA towers
@@ -104,6 +105,7 @@ struct vt_model {
     int stem_stream = -1;  // stem_stream_kernel (all four layers of a frame streamed band by band through one workgroup) instead of
                            // stem_pipe + stem_b (G256) / stem_fused (G128); auto: G256 B > 176 (fp32 build)
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
+    int blocks_bf3 = 1;    // VT_BLOCKS_BF3: the G128 frame form's MLP as exact three-piece bf16 products (0 = fp32 MFMA)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
     int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
@@ -197,6 +199,45 @@ void pack_conv_image(const std::vector<double>& w, int cout, int cin, float* dst
 // The same weights as three-piece bf16 images for vt_head3.h: [oc_tile][chunk pair][piece][64 lanes][8 bf16]; a lane's 8 values
 // are its quad of chunk 2 p, then its quad of chunk 2 p + 1 (zero beyond the last chunk).  w = h + m + l exactly, by truncation
 // (the split the kernels apply to activations: vth3::split3).
+// x = h + m + l by truncation (vt3::split3): the bf16 bit patterns of the three pieces
+void split3_host(float v, uint16_t (&pieces)[3]) {
+    uint32_t xb, r1b, r2b;
+    std::memcpy(&xb, &v, 4);
+    float hf; const uint32_t hb = xb & 0xffff0000u; std::memcpy(&hf, &hb, 4);
+    const float r1 = v - hf; std::memcpy(&r1b, &r1, 4);
+    float mf; const uint32_t mb = r1b & 0xffff0000u; std::memcpy(&mf, &mb, 4);
+    const float r2 = r1 - mf; std::memcpy(&r2b, &r2, 4);
+    pieces[0] = (uint16_t)(xb >> 16); pieces[1] = (uint16_t)(r1b >> 16); pieces[2] = (uint16_t)(r2b >> 16);
+}
+
+// The MLP's weights as three-piece images for the block kernel's BF3 form (layout: vt_blocks.h), from the fp32 operand images
+// [out tile][chunk][64 lanes][4] of the same (folded) weights.
+void pack_mlp_images3(const float* img1, const float* img2, uint16_t* dst) {
+    constexpr int NC = vtb::NC, NH = vtb::NH;
+    uint16_t pcs[3];
+    for (int ot = 0; ot < NH; ++ot) {           // fc1: [ot][ pair 0: piece x lane x 8 | chunk 2: piece x lane x 4 ]
+        uint16_t* o = dst + (size_t)ot * vtb::W3_FC1_OT16 * 8;
+        for (int l = 0; l < 64; ++l) {
+            for (int e = 0; e < 8; ++e) {
+                split3_host(img1[(((size_t)ot * NC + (e >> 2)) * 64 + l) * 4 + (e & 3)], pcs);
+                for (int pc = 0; pc < 3; ++pc) o[((size_t)pc * 64 + l) * 8 + e] = pcs[pc];
+            }
+            for (int e = 0; e < 4; ++e) {
+                split3_host(img1[(((size_t)ot * NC + 2) * 64 + l) * 4 + e], pcs);
+                for (int pc = 0; pc < 3; ++pc) o[(size_t)192 * 8 + ((size_t)pc * 64 + l) * 4 + e] = pcs[pc];
+            }
+        }
+    }
+    uint16_t* d2 = dst + (size_t)vtb::W3_FC1_TILES * 512;
+    for (int ot = 0; ot < NC; ++ot)             // fc2: [ot][pair][piece][lane][8]
+        for (int p = 0; p < NH / 2; ++p)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    split3_host(img2[(((size_t)ot * NH + 2 * p + (e >> 2)) * 64 + l) * 4 + (e & 3)], pcs);
+                    for (int pc = 0; pc < 3; ++pc) d2[((((size_t)ot * (NH / 2) + p) * 3 + pc) * 64 + l) * 8 + e] = pcs[pc];
+                }
+}
+
 void pack_conv_image3(const std::vector<double>& w, int cout, int cin, uint16_t* dst) {
     const int nq = (cin + 3) / 4, nqt = 9 * nq, nch = (nqt + 3) / 4, ncp = (nch + 1) / 2, not_ = (cout + 15) / 16;
     for (int ot = 0; ot < not_; ++ot)
@@ -210,13 +251,8 @@ void pack_conv_image3(const std::vector<double>& w, int cout, int cin, uint16_t*
                         const int tap = Q / nq, ic = 4 * (Q % nq) + r;
                         if (ic < cin) v = (float)w[((size_t)oc * cin + ic) * 9 + tap];
                     }
-                    uint32_t xb, r1b, r2b;
-                    std::memcpy(&xb, &v, 4);
-                    float hf; const uint32_t hb = xb & 0xffff0000u; std::memcpy(&hf, &hb, 4);
-                    const float r1 = v - hf; std::memcpy(&r1b, &r1, 4);
-                    float mf; const uint32_t mb = r1b & 0xffff0000u; std::memcpy(&mf, &mb, 4);
-                    const float r2 = r1 - mf; std::memcpy(&r2b, &r2, 4);
-                    const uint16_t pieces[3] = {(uint16_t)(xb >> 16), (uint16_t)(r1b >> 16), (uint16_t)(r2b >> 16)};
+                    uint16_t pieces[3];
+                    split3_host(v, pieces);
                     for (int pc = 0; pc < 3; ++pc) dst[((((size_t)ot * ncp + cp) * 3 + pc) * 64 + l) * 8 + e] = pieces[pc];
                 }
 }
@@ -401,20 +437,20 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
 
 // dynamic LDS of blocks_kernel<NT, ., ., WLDS, BAL> at a given depth: K/V images, weight staging buffers,
 // the small parameters (LayerNorm vectors + biases of every block) and the guests' exchange area
-size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth) {
-    return ((size_t)2 * NT * vtb::NC + (WLDS ? 2 * vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
+size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth, bool BF3 = false) {
+    return ((size_t)2 * NT * vtb::NC + (WLDS ? (BF3 ? vtb::W3_FC1_TILES : vtb::WBUF_TILES) + vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
            (size_t)vtb::small_floats(depth) * sizeof(float) +
            (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 64 : 0);
 }
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false>
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode) {
     if (zcache_mode != 0 && !ZC)
         return fail(VT_ERR_STATE, "the template cache needs the default block kernel (VT_BLOCKS_BAL = 1)");
-    const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth);
-    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
-                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode);
+    const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth, BF3);
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC, BF3>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode, m->blocks3.p);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -463,6 +499,11 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
                         : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc, f0);
     switch (m->L / 16) {
         case 5:
+#ifndef VT_F16
+            if (m->blocks_bal && m->blocks_bf3)
+                return zc ? launch_blocks<5, 8, 1, true, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                          : launch_blocks<5, 8, 1, true, true, false, true>(m, st, tokens, B, nblocks, feat, resid, zc);
+#endif
             if (m->blocks_bal) return zc ? launch_blocks<5, 8, 1, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                                          : launch_blocks<5, 8, 1, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
             return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid, zc)
@@ -761,6 +802,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
+    m->blocks_bf3 = env_int("VT_BLOCKS_BF3", 1);
+    // the BF3 form's staging buffers are 18 KiB larger: beyond depth 8 its small parameters no longer fit beside them -> fp32 form
+    if (blocks_lds_bytes(5, true, true, cfg->depth, true) > LDS_PER_CU) m->blocks_bf3 = 0;
     m->stem_fused = env_int("VT_STEM_FUSED", -1);
     m->stem_pipe = env_int("VT_STEM_PIPE", -1);
     m->stem_stream = env_int("VT_STEM_STREAM", -1);
@@ -807,6 +851,14 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth));
+#ifndef VT_F16
+        if (e == hipSuccess && m->blocks_bf3)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth, true));
+        if (e == hipSuccess && m->blocks_bf3)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth, true));
+#endif
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
@@ -859,7 +911,7 @@ void vt_destroy(vt_model* m) {
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
     m->act_x.release(); m->act_z.release();
-    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
+    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->blocks3, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
@@ -918,6 +970,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     if ((rc = upload(m->pos_x, std::vector<float>(p, p + (size_t)m->len_x * C)))) return rc;
     // ---- transformer blocks + final norm
     std::vector<float> bp((size_t)m->cfg.depth * vtb::BLOCK_STRIDE + 2 * C);
+    std::vector<uint16_t> bp3((size_t)m->cfg.depth * vtb::BLOCK3_STRIDE * 2);
     for (int b = 0; b < m->cfg.depth; ++b) {
         const std::string pre = "blocks." + std::to_string(b) + ".";
         float* dst = bp.data() + (size_t)b * vtb::BLOCK_STRIDE;
@@ -954,6 +1007,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
+        pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
     }
     {
         float* dst = bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;
@@ -963,6 +1017,11 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + C, p, C * sizeof(float));
     }
     if ((rc = upload(m->blocks, bp))) return rc;
+    {
+        std::vector<float> as_f(bp3.size() / 2);
+        std::memcpy(as_f.data(), bp3.data(), bp3.size() * 2);
+        if ((rc = upload(m->blocks3, as_f))) return rc;
+    }
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
 #ifndef VT_F16

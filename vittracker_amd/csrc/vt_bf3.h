@@ -1,0 +1,63 @@
+// vt_bf3.h -- fp32 products on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces, x = h + m + l
+// (8 mantissa bits each, by truncation: every residual is an exact fp32 subtraction), and a product a b is the six terms
+// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16; what is dropped (ml, lm, ll) is below 2^-23 of
+// |a b|, the rounding of an fp32 MFMA itself (tools/src/probe_bf3.hip, on the hardware: max error / sum |a b| 2.6e-7 against
+// 3.0e-7 for v_mfma_f32_16x16x4_f32).  Six 16 x 16 x 32 instructions cover EIGHT times the K of a 16 x 16 x 4 fp32 MFMA in
+// 6 x 16 cycles against 8 x 32, and VALU work issues beside them.  Shared by vt_head3.h (towers) and vt_blocks.h (MLP).
+//
+// Operand convention: a lane's 8 bf16 of a K = 32 instruction are its quad (k = 4 q + 0..3, vt_common.h) of 16-deep chunk 2 p,
+// then its quad of chunk 2 p + 1 -- the K order inside an MFMA is free as long as both operands agree -- so the fp32 kernels'
+// chunking carries over unchanged; an odd last chunk pairs with zeros.
+#pragma once
+#include "vt_common.h"
+
+namespace vt3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l.  Element r of a result piece = bf16 bits of x[r]'s piece; two elements per dword, low half first.
+__device__ __forceinline__ void split3(f4 x, u32x2& h, u32x2& m, u32x2& l) {
+    unsigned xb[4], r1b[4], r2b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xb[i] = __float_as_uint(x[i]);
+        const float r1 = x[i] - __uint_as_float(xb[i] & 0xffff0000u);
+        r1b[i] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(r1b[i] & 0xffff0000u);
+        r2b[i] = __float_as_uint(r2);
+    }
+    h = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+    m = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+    l = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+}
+// the fp32 value back from its pieces (exact: h + m has at most 16 significant bits, + l at most 24)
+__device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {
+    f4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned sh = (i & 1) ? 0u : 16u;
+        const float fh = __uint_as_float((h[i >> 1] << sh) & 0xffff0000u), fm = __uint_as_float((m[i >> 1] << sh) & 0xffff0000u),
+                    fl = __uint_as_float((l[i >> 1] << sh) & 0xffff0000u);
+        v[i] = (fh + fm) + fl;
+    }
+    return v;
+}
+
+__device__ __forceinline__ f4 mma(u32x4 a, u32x4 b, f4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// the three small terms (l h, h l, m m), then the three large ones (m h, h m, h h), of one K = 32 step: pieces [0] = h, [1] = m, [2] = l
+__device__ __forceinline__ f4 mma_small(const u32x4 (&a)[3], const u32x4 (&b)[3], f4 acc) {
+    acc = mma(a[2], b[0], acc);
+    acc = mma(a[0], b[2], acc);
+    return mma(a[1], b[1], acc);
+}
+__device__ __forceinline__ f4 mma_large(const u32x4 (&a)[3], const u32x4 (&b)[3], f4 acc) {
+    acc = mma(a[1], b[0], acc);
+    acc = mma(a[0], b[1], acc);
+    return mma(a[0], b[0], acc);
+}
+
+}  // namespace vt3

@@ -21,6 +21,7 @@
 #pragma once
 #include <type_traits>
 #include "vt_common.h"
+#include "vt_bf3.h"
 
 namespace vtb {
 
@@ -45,6 +46,16 @@ constexpr int O_W2 = O_B1 + HID;                   // 3 x 12 tiles
 constexpr int O_B2 = O_W2 + NC * NH * 256;
 constexpr int BLOCK_STRIDE = O_B2 + C;             // 28272 floats
 static_assert(BLOCK_STRIDE % 4 == 0 && O_WQKV % 4 == 0 && O_W1 % 4 == 0 && O_W2 % 4 == 0, "16B alignment");
+
+// BF3 (G128 frame form): the MLP's two GEMMs -- 52 % of a block's MACs -- run on the bf16 matrix pipe as exact three-piece
+// products (vt_bf3.h).  Their weights come from a second parameter buffer of pre-split images, per block:
+//   fc1 (K = 48 = a chunk pair + one odd chunk): [out tile 12][ pair 0: piece 3 x 64 lanes x 16 B | chunk 2: piece 3 x 64 lanes x 8 B ]  = 54 KiB
+//   fc2 (K = 192 = 6 chunk pairs):               [out tile 3][pair 6][piece 3][64 lanes x 16 B]                                     = 54 KiB
+constexpr int W3_FC1_TILES = NH * 3 + NH * 3 / 2;     // KiB tiles (the LDS-DMA unit)
+constexpr int W3_FC1_OT16 = 3 * 64 + 3 * 32;          // 16-byte units per output tile (288)
+constexpr int W3_FC2_TILES = NC * (NH / 2) * 3;
+constexpr int BLOCK3_STRIDE = (W3_FC1_TILES + W3_FC2_TILES) * 256;      // floats
+static_assert(W3_FC1_TILES == 54 && W3_FC2_TILES == 54 && NH * W3_FC1_OT16 == W3_FC1_TILES * 64, "three-piece MLP images");
 
 // The small parameters of a block (LayerNorm gamma / beta and the four bias vectors, 624 floats) are
 // copied to LDS once when the kernel starts.  Read from global memory where they are used -- as the
@@ -146,7 +157,11 @@ __device__ __forceinline__ void barrier_publish() {
     __syncthreads();
 }
 
+#ifndef VT_BLK_NOSTAGE
+#define VT_BLK_NOSTAGE 0       // timing experiment only (wrong results): 1 = no weight staging at all
+#endif
 __device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ src, int ntiles, int w, int nw, int lane) {
+    if (VT_BLK_NOSTAGE) return;
     for (int t = w; t < ntiles; t += nw)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)t * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(dst + t * 64), 16, 0, 0);
@@ -198,7 +213,7 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
 //     fc2         K-split: guest g contracts its own hidden tiles -> partial in LDS; summed (36)
 // Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream that
 // fills the owner's waits (f32 MFMA and VALU issue add up even across waves: tools/src/probe_overlap.hip).
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false>   // ZC: template-cache variant (config 5)
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false>   // ZC: template-cache variant (config 5); BF3: MLP on the bf16 pipe
 __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
@@ -210,8 +225,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                                                          // frame-invariant (the template tokens are; LN and the projections act per token).
                                                          // [B][len_z/16][9][64] f4: q, k, v^T images of each template tile.
                                                          float* __restrict__ zcache,
-                                                         int zcache_mode) {   // 0: off, 1: compute and store, 2: load instead of computing
+                                                         int zcache_mode,     // 0: off, 1: compute and store, 2: load instead of computing
+                                                         const float* __restrict__ params3) {   // BF3: the MLP's three-piece images, BLOCK3_STRIDE per block
     static_assert(NW * TPW >= NT, "tiles must be covered");
+    static_assert(!BF3 || (BAL && 2 * NT * NC >= W3_FC2_TILES - WBUF_TILES), "BF3: written for the balanced frame form; fc2's third output tile is staged in the K / V area");
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
     constexpr int L = NT * 16;
     constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
@@ -220,7 +237,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]
     f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
     f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
-    f4* Wb = Wa + WBUF_TILES * 64;                         // WLDS: [36][64] staging buffer B
+    constexpr int WA_TILES = BF3 ? W3_FC1_TILES : WBUF_TILES;      // BF3: fc1's three-piece image is 54 KiB
+    f4* Wb = Wa + WA_TILES * 64;                           // WLDS: [36][64] staging buffer B (BF3: fc2's output tiles 0 and 1; tile 2 goes to the K / V area, free during the MLP)
     float* Sp = reinterpret_cast<float*>(WLDS ? Wb + WBUF_TILES * 64 : Wa);   // small parameters, small_floats(depth)
     // BAL: guest exchange areas
     f4* Qg = reinterpret_cast<f4*>(Sp + small_floats(depth_total));   // [NC][64]      q of the guest tile
@@ -279,7 +297,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     }
     barrier_publish<WLDS>();
 
+    const int lane_k = lane;
     for (int blk = 0; blk < nblocks; ++blk) {
+        // BF3: every per-lane address inside a block is derived from a fresh (opaque) copy of the lane index -- the kernel sits at the
+        // 256-register cap, and as invariants of the block loop hipcc computed ~40 LDS addresses up front and spilled them; their
+        // reloads wait on vmcnt, i.e. on the weight staging in flight.  Recomputing them costs a few dozen VALU instructions per block.
+        int lane_s = lane_k;
+        if constexpr (BF3) asm volatile("" : "+v"(lane_s));
+        const int lane = lane_s, tok = lane & 15, q = lane >> 4;
         const float* __restrict__ P = params + (size_t)blk * BLOCK_STRIDE;
         const float* S = Sp + blk * SMALL_STRIDE;
         // weight operand image `t` of each GEMM: from the staging buffers (WLDS) or straight from L2
@@ -287,7 +312,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         auto w_proj = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_WPROJ, t, lane); };
         auto w_fc1 = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_W1, t, lane); };
         auto w_fc2 = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_W2, t, lane); };
-        if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
+        // BF3 staging: the same four bursts per block as the fp32 form, issued by all eight waves at the start of the phase before the
+        // one that reads them (fc1 54 KiB -> Wa during attention; fc2 36 KiB -> Wb + 18 KiB -> the K / V area during the fc1 phase).
+        // A burst is not free for the waves that issue it -- with staging compiled out (VT_BLK_NOSTAGE) the BF3 kernel takes 36.4
+        // instead of 40.5 us, the fp32 one 41.4 instead of 43.5 -- but every other placement measured slower or equal.
+        const float* __restrict__ P3 = BF3 ? params3 + (size_t)blk * BLOCK3_STRIDE : nullptr;
+        constexpr int QKV_TILES = 9 * NC, PROJ_TILES = NC * NC;
+        if constexpr (BF3) {
+            stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane);
+        } else if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
 
         f4 qr[TPW][NC];
         // ---- LN1 + QKV; publish K / V^T images ------------------------------------------------
@@ -381,7 +414,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         stamp();            // QKV done
         barrier_publish<WLDS>();    // K/V published; proj weights landed; buffer A free
         stamp();
-        if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
+        if constexpr (BF3) {
+            stage_tiles(Wa, P3, W3_FC1_TILES, w, NW, lane);
+        } else if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
         // output, proj and MLP never reach the head (vit_dist.py:126 keeps the search rows only),
         // so those tiles stop after publishing K / V -- unless the caller asked for the residual.
@@ -551,7 +586,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         stamp();            // attention + proj done
         barrier_publish<WLDS>();    // K/V and buffer B free; fc1 weights landed
         stamp();
-        if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
+        if constexpr (BF3) {
+            stage_tiles(Wb, P3 + W3_FC1_TILES * 256, WBUF_TILES, w, NW, lane);                                          // fc2, output tiles 0 and 1
+            stage_tiles(Kimg, P3 + (W3_FC1_TILES + WBUF_TILES) * 256, W3_FC2_TILES - WBUF_TILES, w, NW, lane);           // output tile 2
+        } else if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
         // ---- LN2 + MLP (residual add) ---------------------------------------------------------
         // fc1 -> GELU -> fc2 in three groups of HG = 4 hidden tiles, software-pipelined so GELU (VALU)
         // of one group issues in the shadow of the next group's MFMAs:
@@ -614,7 +652,241 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             fstamp();
             fc2(hid[hi], 2, x[i]);
         };
-        if constexpr (WLDS) {
+        // ---- BF3: the same MLP as exact three-piece bf16 products (vt_bf3.h).  fc1 walks the 12 hidden tiles in units of two
+        // (two independent accumulator chains; 12 MFMAs per tile: six terms on chunk pair (0, 1), six on chunk 2 with a zero
+        // upper half), the next unit's weight pieces requested ahead, GELU + the split of the previous unit under the current
+        // unit's MFMAs.  Unit u's two hidden tiles ARE fc2's chunk pair u, so the split results are fc2's B operands as they stand.
+        using vt3::u32x2;
+        using vt3::u32x4;
+        // the images' per-lane addresses are built from a fresh copy of the lane index in every block: as invariants of the block
+        // loop hipcc computed ~38 of them up front and spilled them (reloads wait on vmcnt, i.e. on the weight staging in flight)
+        int lane3 = lane;
+        if constexpr (BF3) asm volatile("" : "+v"(lane3));
+        const u32x4* const Wa3 = reinterpret_cast<const u32x4*>(Wa);
+        const u32x2* const Wa3h = reinterpret_cast<const u32x2*>(Wa);
+        const u32x4* const Wb3 = reinterpret_cast<const u32x4*>(Wb);
+        const u32x4* const Wk3 = reinterpret_cast<const u32x4*>(Kimg);
+        auto w1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {       // fc1 pieces of output tile t: chunk pair 0, chunk 2
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a0[pc] = Wa3[t * W3_FC1_OT16 + pc * 64 + lane3];
+                const u32x2 v = Wa3h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+            }
+        };
+        auto w2_load3 = [&](int p, u32x4 (&a)[NC][3]) {                     // fc2 pieces of chunk pair p, all three output tiles
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    a[ot][pc] = ot < 2 ? Wb3[((ot * (NH / 2) + p) * 3 + pc) * 64 + lane3] : Wk3[(p * 3 + pc) * 64 + lane3];
+        };
+        auto split_h3 = [&](const f4 (&h)[NC], u32x4 (&hb)[3], u32x4 (&hc)[3]) {       // LN2's output as fc1's B operands
+            u32x2 a[3], b2[3], c[3];
+            vt3::split3(h[0], a[0], a[1], a[2]);
+            vt3::split3(h[1], b2[0], b2[1], b2[2]);
+            vt3::split3(h[2], c[0], c[1], c[2]);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                hb[pc] = u32x4{a[pc].x, a[pc].y, b2[pc].x, b2[pc].y};
+                hc[pc] = u32x4{c[pc].x, c[pc].y, 0u, 0u};
+            }
+        };
+        // N chains x 12 MFMAs: the small terms of both K steps first, then the large ones
+        auto fc1_terms3 = [&](auto nc, const u32x4 (*a0)[3], const u32x4 (*a2)[3], const u32x4 (&hb)[3], const u32x4 (&hc)[3], f4* acc) {
+            constexpr int N = decltype(nc)::value;
+            constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            const int e = 3 * half + t3;
+                            acc[j] = k == 0 ? vt3::mma(a2[j][TW[e]], hc[TX[e]], acc[j]) : vt3::mma(a0[j][TW[e]], hb[TX[e]], acc[j]);
+                        }
+        };
+        u32x4 hq[NHID][NH / 2][3];       // GELU(fc1) as pieces: [chunk pair][piece] = {quad of chunk 2 p | quad of chunk 2 p + 1}
+        auto mlp_first3 = [&](int i, int hi) {
+            f4 h[NC];
+            layer_norm_plain(x[i], h);
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
+            u32x4 hb[3], hc[3];
+            split_h3(h, hb, hc);
+            fstamp();
+            // one hidden tile per step, its 12 MFMAs as two independent chains (chunk pair 0 onto the bias, chunk 2 onto zero) that
+            // are added afterwards: the next tile's 18 weight registers are requested a step ahead (36 in flight, not 72).  GELU + the
+            // split of the PREVIOUS tile (48 VALU instructions) are written out as six stages of ~8, one behind each pair of MFMAs,
+            // with a scheduling barrier per stage: left to itself hipcc issues the 12 MFMAs as one block (the wave then sits on the
+            // accumulator chains for ~190 cycles with nothing else to issue) and the VALU work behind it; sched_group_barrier
+            // requests did not change that here, and without the asm pin LLVM sinks the whole chain below the following tiles.
+            constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            u32x4 a0[2][3], a2[2][3];
+            w1_load3(0, a0[0], a2[0]);
+            f4 prev = splat4(0.f);
+            u32x2 pl[3];            // pieces of the pair's first tile
+            f2 ua, ub, na, nb, pa, pb, ea, eb;      // GELU state between stages (pairs (x, y) and (z, w) of `prev`)
+            unsigned xb[4], r1b[4], r2b[4];
+            auto gstage = [&](int e) {
+                const auto fma2 = [](f2 p, f2 n, float c) { return __builtin_elementwise_fma(p, n, f2{c, c}); };
+                if (e == 0) {
+                    ua = f2{prev.x, prev.y}; ub = f2{prev.z, prev.w};
+                    na = f2{__builtin_fmaxf(-__builtin_fabsf(ua.x), -6.5f), __builtin_fmaxf(-__builtin_fabsf(ua.y), -6.5f)};
+                    nb = f2{__builtin_fmaxf(-__builtin_fabsf(ub.x), -6.5f), __builtin_fmaxf(-__builtin_fabsf(ub.y), -6.5f)};
+                    pa = __builtin_elementwise_fma(na, f2{2.992413958e-05f, 2.992413958e-05f}, f2{7.398738213e-04f, 7.398738213e-04f});
+                    pb = __builtin_elementwise_fma(nb, f2{2.992413958e-05f, 2.992413958e-05f}, f2{7.398738213e-04f, 7.398738213e-04f});
+                    pa = fma2(pa, na, 7.977461502e-03f); pb = fma2(pb, nb, 7.977461502e-03f);
+                } else if (e == 1) {
+                    pa = fma2(pa, na, 5.323818492e-02f); pb = fma2(pb, nb, 5.323818492e-02f);
+                    pa = fma2(pa, na, -4.589156874e-01f); pb = fma2(pb, nb, -4.589156874e-01f);
+                    pa = fma2(pa, na, 1.151147082e+00f); pb = fma2(pb, nb, 1.151147082e+00f);
+                    pa = fma2(pa, na, -1.0f); pb = fma2(pb, nb, -1.0f);
+                } else if (e == 2) {
+                    ea = f2{__builtin_amdgcn_exp2f(pa.x), __builtin_amdgcn_exp2f(pa.y)};
+                    eb = f2{__builtin_amdgcn_exp2f(pb.x), __builtin_amdgcn_exp2f(pb.y)};
+                    ua = f2{fmaxf(ua.x, 0.0f), fmaxf(ua.y, 0.0f)};
+                    ub = f2{fmaxf(ub.x, 0.0f), fmaxf(ub.y, 0.0f)};
+                } else if (e == 3) {
+                    const f2 ga = __builtin_elementwise_fma(na, ea, ua), gb = __builtin_elementwise_fma(nb, eb, ub);
+                    const float gv[4] = {ga.x, ga.y, gb.x, gb.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xb[k] = __float_as_uint(gv[k]);
+                        r1b[k] = __float_as_uint(gv[k] - __uint_as_float(xb[k] & 0xffff0000u));
+                    }
+                } else if (e == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r2b[k] = __float_as_uint(__uint_as_float(r1b[k]) - __uint_as_float(r1b[k] & 0xffff0000u));
+                }
+            };
+            auto gfinish = [&](int t) {      // the six packs; t = the tile the pieces belong to
+                u32x2 pc3[3];
+                pc3[0] = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+                pc3[1] = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+                pc3[2] = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pc3[pc]));
+                if (t & 1) {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) hq[hi][t >> 1][pc] = u32x4{pl[pc].x, pl[pc].y, pc3[pc].x, pc3[pc].y};
+                } else {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) pl[pc] = pc3[pc];
+                }
+            };
+#pragma unroll
+            for (int t = 0; t <= NH; ++t) {
+                if (t == 4 || t == 8) fstamp();
+                f4 accA = splat4(0.f), accB = splat4(0.f);
+                if (t < NH) {
+                    if (t + 1 < NH) w1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                    accA = ld4(S + S_B1 + 16 * t + 4 * q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    if (t < NH) {
+                        accB = vt3::mma(a2[t & 1][TW[e]], hc[TX[e]], accB);
+                        accA = vt3::mma(a0[t & 1][TW[e]], hb[TX[e]], accA);
+                    }
+                    if (t > 0) {
+                        if (e < 5) gstage(e);
+                        else gfinish(t - 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                prev = accA + accB;
+            }
+        };
+        auto mlp_second3 = [&](int i, int hi) {
+            constexpr int NP = NH / 2;
+            constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            u32x4 a[2][NC][3];
+            w2_load3(0, a[0]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (p + 1 < NP) w2_load3(p + 1, a[(p + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 6; ++e)
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) x[i][ot] = vt3::mma(a[p & 1][ot][TW[e]], hq[hi][p][TX[e]], x[i][ot]);
+                if (p == 1 || p == 3) fstamp();
+            }
+        };
+        if constexpr (BF3) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int T = w + NW * i;
+                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first3(i, i);
+            }
+            u32x2 gq[NC][3];     // the guest's GELU(fc1) tiles 3 g .. 3 g + 2 as pieces
+            if (w >= NOWN) {
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q) + Dg[ot * 64 + lane];
+                f4 h[NC];
+                layer_norm_plain(x4, h);
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
+                u32x4 hb[3], hc[3];
+                split_h3(h, hb, hc);
+                u32x4 a0[NC][3], a2[NC][3];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) w1_load3(NC * g + j, a0[j], a2[j]);
+                f4 acc[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = ld4(S + S_B1 + 16 * (NC * g + j) + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);
+                fc1_terms3(std::integral_constant<int, NC>{}, a0, a2, hb, hc, acc);
+#pragma unroll
+                for (int j = 0; j < NC; ++j) vt3::split3(gelu4(acc[j]), gq[j][0], gq[j][1], gq[j][2]);
+            }
+                stamp();            // fc1 done
+            barrier_publish<true>();    // fc2 weights landed; buffer A free
+            if (blk + 1 < nblocks) stage_tiles(Wa, P + BLOCK_STRIDE + O_WQKV, QKV_TILES, w, NW, lane);   // next block's qkv
+            stamp();
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int T = w + NW * i;
+                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second3(i, i);
+            }
+            if (w >= NOWN) {
+                // fc2 restricted to this guest's hidden tiles 3 g .. 3 g + 2 = one whole chunk pair and half of another (the other
+                // half of that pair belongs to the neighbouring guest: zeros in this guest's B operand)
+                const bool odd = g & 1;
+                const int p_full = (3 * g + (odd ? 1 : 0)) >> 1, p_half = (3 * g + (odd ? 0 : 2)) >> 1;
+                u32x4 bf[3], bh[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    bf[pc] = odd ? u32x4{gq[1][pc].x, gq[1][pc].y, gq[2][pc].x, gq[2][pc].y} : u32x4{gq[0][pc].x, gq[0][pc].y, gq[1][pc].x, gq[1][pc].y};
+                    bh[pc] = odd ? u32x4{0u, 0u, gq[0][pc].x, gq[0][pc].y} : u32x4{gq[2][pc].x, gq[2][pc].y, 0u, 0u};
+                }
+                u32x4 af[NC][3], ah[NC][3];
+                w2_load3(p_full, af);
+                w2_load3(p_half, ah);
+                f4 part[NC];
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                            for (int ot = 0; ot < NC; ++ot) {
+                                const int e = 3 * half + t3;
+                                part[ot] = k == 0 ? vt3::mma(ah[ot][TW[e]], bh[TX[e]], part[ot]) : vt3::mma(af[ot][TW[e]], bf[TX[e]], part[ot]);
+                            }
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) Pg[(g * NC + ot) * 64 + lane] = part[ot];
+            }
+        } else if constexpr (WLDS) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;

@@ -19,6 +19,7 @@
 //     operands agree), so the fp32 kernels' 16-deep chunks, quad decoding and tap offsets carry over unchanged.
 //   * an odd last chunk pairs with zero weights (the activation read for it clamps to a valid quad, as pad quads always did).
 #pragma once
+#include "vt_bf3.h"
 #include "vt_head.h"
 
 #ifndef VT_F16
@@ -31,9 +32,11 @@ using vth::C;
 using vth::W1;
 using vth::nchunks;
 using vth::ntiles;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+using vt3::bf16x8;
+using vt3::u32x2;
+using vt3::u32x4;
+using vt3::split3;
+using vt3::join3;
 using G = vth::Geo<8>;
 
 constexpr int npairs(int cin) { return (nchunks(cin) + 1) / 2; }
@@ -44,35 +47,6 @@ constexpr int O3_W2 = O3_W1 + img16(48, 32);
 constexpr int O3_W3 = O3_W2 + img16(32, 16);
 constexpr int O3_W4 = O3_W3 + img16(16, 8);
 constexpr int TOWER3_STRIDE = O3_W4 + img16(8, 4);      // 16-byte units
-
-// x = h + m + l exactly (truncating pieces: every residual is computed without rounding).  Element r of the result pieces =
-// bf16 bits of x[r]'s piece; two elements per dword, low half first.
-__device__ __forceinline__ void split3(f4 x, u32x2& h, u32x2& m, u32x2& l) {
-    unsigned xb[4], r1b[4], r2b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        xb[i] = __float_as_uint(x[i]);
-        const float r1 = x[i] - __uint_as_float(xb[i] & 0xffff0000u);
-        r1b[i] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(r1b[i] & 0xffff0000u);
-        r2b[i] = __float_as_uint(r2);
-    }
-    h = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
-    m = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
-    l = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
-}
-// the fp32 value back from its pieces (exact: h + m has at most 16 significant bits, + l at most 24)
-__device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {
-    f4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned sh = (i & 1) ? 0u : 16u;
-        const float fh = __uint_as_float((h[i >> 1] << sh) & 0xffff0000u), fm = __uint_as_float((m[i >> 1] << sh) & 0xffff0000u),
-                    fl = __uint_as_float((l[i >> 1] << sh) & 0xffff0000u);
-        v[i] = (fh + fm) + fl;
-    }
-    return v;
-}
 
 // One 3x3 stride-1 conv + bias + ReLU between two piece-planar LDS maps.  Work split over the NW waves of a tower as in
 // vth::HeadConv: a 2-output-tile layer gives each wave one output tile and half of the pixel tiles, 1-tile layers split the
