@@ -212,9 +212,29 @@ void split3_host(float v, uint16_t (&pieces)[3]) {
 
 // The MLP's weights as three-piece images for the block kernel's BF3 form (layout: vt_blocks.h), from the fp32 operand images
 // [out tile][chunk][64 lanes][4] of the same (folded) weights.
-void pack_mlp_images3(const float* img1, const float* img2, uint16_t* dst) {
+// a K = 48 layer (fc1, qkv) from its fp32 operand image [ot][chunk 3][64 lanes][4]: [ot][ pair 0: piece x lane x 8 | chunk 2: piece x lane x 4 ]
+void pack_k48_image3(const float* img1, int ntiles, uint16_t* dst) {
+    constexpr int NC = vtb::NC;
+    uint16_t pcs[3];
+    for (int ot = 0; ot < ntiles; ++ot) {
+        uint16_t* o = dst + (size_t)ot * vtb::W3_FC1_OT16 * 8;
+        for (int l = 0; l < 64; ++l) {
+            for (int e = 0; e < 8; ++e) {
+                split3_host(img1[(((size_t)ot * NC + (e >> 2)) * 64 + l) * 4 + (e & 3)], pcs);
+                for (int pc = 0; pc < 3; ++pc) o[((size_t)pc * 64 + l) * 8 + e] = pcs[pc];
+            }
+            for (int e = 0; e < 4; ++e) {
+                split3_host(img1[(((size_t)ot * NC + 2) * 64 + l) * 4 + e], pcs);
+                for (int pc = 0; pc < 3; ++pc) o[(size_t)192 * 8 + ((size_t)pc * 64 + l) * 4 + e] = pcs[pc];
+            }
+        }
+    }
+}
+
+void pack_mlp_images3(const float* img1, const float* img2, const float* imgqkv, uint16_t* dst) {
     constexpr int NC = vtb::NC, NH = vtb::NH;
     uint16_t pcs[3];
+    pack_k48_image3(imgqkv, 9, dst + (size_t)(vtb::W3_FC1_TILES + vtb::W3_FC2_TILES) * 512);
     for (int ot = 0; ot < NH; ++ot) {           // fc1: [ot][ pair 0: piece x lane x 8 | chunk 2: piece x lane x 4 ]
         uint16_t* o = dst + (size_t)ot * vtb::W3_FC1_OT16 * 8;
         for (int l = 0; l < 64; ++l) {
@@ -970,7 +990,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     if ((rc = upload(m->pos_x, std::vector<float>(p, p + (size_t)m->len_x * C)))) return rc;
     // ---- transformer blocks + final norm
     std::vector<float> bp((size_t)m->cfg.depth * vtb::BLOCK_STRIDE + 2 * C);
-    std::vector<uint16_t> bp3((size_t)m->cfg.depth * vtb::BLOCK3_STRIDE * 2);
+    std::vector<uint16_t> bp3((size_t)m->cfg.depth * vtb::BLOCK3_STRIDE * 2, 0);
     for (int b = 0; b < m->cfg.depth; ++b) {
         const std::string pre = "blocks." + std::to_string(b) + ".";
         float* dst = bp.data() + (size_t)b * vtb::BLOCK_STRIDE;
@@ -1007,7 +1027,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
-        pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
+        pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, dst + vtb::O_WQKV, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
     }
     {
         float* dst = bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;

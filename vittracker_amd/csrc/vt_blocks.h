@@ -51,10 +51,15 @@ static_assert(BLOCK_STRIDE % 4 == 0 && O_WQKV % 4 == 0 && O_W1 % 4 == 0 && O_W2 
 // products (vt_bf3.h).  Their weights come from a second parameter buffer of pre-split images, per block:
 //   fc1 (K = 48 = a chunk pair + one odd chunk): [out tile 12][ pair 0: piece 3 x 64 lanes x 16 B | chunk 2: piece 3 x 64 lanes x 8 B ]  = 54 KiB
 //   fc2 (K = 192 = 6 chunk pairs):               [out tile 3][pair 6][piece 3][64 lanes x 16 B]                                     = 54 KiB
+//   qkv (K = 48; LN1 folded), fc1's layout:      [out tile 9: q 0-2, k 3-5, v 6-8][ pair 0 | chunk 2 ]                              = 40.5 KiB
+// (v: the operands swap roles -- tokens as rows, so V lands transposed -- which the 16 x 16 x 32 instruction's identical A / B
+// register layouts make free: the same image serves.)  proj (9 KiB) and the attention products stay on fp32 MFMAs: K / V^T as
+// pieces would need 15 KiB more LDS than the CU has left.
 constexpr int W3_FC1_TILES = NH * 3 + NH * 3 / 2;     // KiB tiles (the LDS-DMA unit)
 constexpr int W3_FC1_OT16 = 3 * 64 + 3 * 32;          // 16-byte units per output tile (288)
 constexpr int W3_FC2_TILES = NC * (NH / 2) * 3;
-constexpr int BLOCK3_STRIDE = (W3_FC1_TILES + W3_FC2_TILES) * 256;      // floats
+constexpr int W3_QKV_TILES = (9 * W3_FC1_OT16 + 63) / 64;                // qkv (K = 48, 9 output tiles) in fc1's layout: 40.5 KiB, staged as 41
+constexpr int BLOCK3_STRIDE = (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 256;      // floats: [fc1 | fc2 | qkv]
 static_assert(W3_FC1_TILES == 54 && W3_FC2_TILES == 54 && NH * W3_FC1_OT16 == W3_FC1_TILES * 64, "three-piece MLP images");
 
 // The small parameters of a block (LayerNorm gamma / beta and the four bias vectors, 624 floats) are
@@ -269,7 +274,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     };
     auto fstamp = [&]() { if (fine) stamp(); };     // per-stage stamps (VT_DBG_STAMPS=2)
     stamp();
-    if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
+    if constexpr (BF3) stage_tiles(Wa, params3 + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);
+    else if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
     for (int i = threadIdx.x; 4 * i < small_floats(depth_total); i += NW * 64)
         st4(Sp + 4 * i, ld4(params + small_src(4 * i, depth_total)));
 
@@ -317,7 +323,56 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         // A burst is not free for the waves that issue it -- with staging compiled out (VT_BLK_NOSTAGE) the BF3 kernel takes 36.4
         // instead of 40.5 us, the fp32 one 41.4 instead of 43.5 -- but every other placement measured slower or equal.
         const float* __restrict__ P3 = BF3 ? params3 + (size_t)blk * BLOCK3_STRIDE : nullptr;
-        constexpr int QKV_TILES = 9 * NC, PROJ_TILES = NC * NC;
+        constexpr int PROJ_TILES = NC * NC;
+        using vt3::u32x2;
+        using vt3::u32x4;
+        // the images' per-lane addresses are built from a fresh copy of the lane index in every block: as invariants of the block
+        // loop hipcc computed ~38 of them up front and spilled them (reloads wait on vmcnt, i.e. on the weight staging in flight)
+        int lane3 = lane;
+        if constexpr (BF3) asm volatile("" : "+v"(lane3));
+        const u32x4* const Wa3 = reinterpret_cast<const u32x4*>(Wa);
+        const u32x2* const Wa3h = reinterpret_cast<const u32x2*>(Wa);
+        const u32x4* const Wb3 = reinterpret_cast<const u32x4*>(Wb);
+        const u32x4* const Wk3 = reinterpret_cast<const u32x4*>(Kimg);
+        auto w1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {       // fc1 pieces of output tile t: chunk pair 0, chunk 2
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a0[pc] = Wa3[t * W3_FC1_OT16 + pc * 64 + lane3];
+                const u32x2 v = Wa3h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+            }
+        };
+        auto w2_load3 = [&](int p, u32x4 (&a)[NC][3]) {                     // fc2 pieces of chunk pair p, all three output tiles
+#pragma unroll
+            for (int ot = 0; ot < NC; ++ot)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    a[ot][pc] = ot < 2 ? Wb3[((ot * (NH / 2) + p) * 3 + pc) * 64 + lane3] : Wk3[(p * 3 + pc) * 64 + lane3];
+        };
+        auto split_h3 = [&](const f4 (&h)[NC], u32x4 (&hb)[3], u32x4 (&hc)[3]) {       // LN2's output as fc1's B operands
+            u32x2 a[3], b2[3], c[3];
+            vt3::split3(h[0], a[0], a[1], a[2]);
+            vt3::split3(h[1], b2[0], b2[1], b2[2]);
+            vt3::split3(h[2], c[0], c[1], c[2]);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                hb[pc] = u32x4{a[pc].x, a[pc].y, b2[pc].x, b2[pc].y};
+                hc[pc] = u32x4{c[pc].x, c[pc].y, 0u, 0u};
+            }
+        };
+        // one 16 x 16 output tile of a K = 48 layer: 12 MFMAs as two chains (chunk pair 0 onto `init`, chunk 2 onto zero), added.
+        // SWAP: the activation pieces are the A operand (rows = tokens): v, so that V^T comes out.
+        auto tile48 = [&](auto swap, const u32x4 (&a0)[3], const u32x4 (&a2)[3], const u32x4 (&hb)[3], const u32x4 (&hc)[3], f4 init) {
+            constexpr bool SWAP = decltype(swap)::value;
+            constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            f4 accA = init, accB = splat4(0.f);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                accB = SWAP ? vt3::mma(hc[TX[e]], a2[TW[e]], accB) : vt3::mma(a2[TW[e]], hc[TX[e]], accB);
+                accA = SWAP ? vt3::mma(hb[TX[e]], a0[TW[e]], accA) : vt3::mma(a0[TW[e]], hb[TX[e]], accA);
+            }
+            return accA + accB;
+        };
         if constexpr (BF3) {
             stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane);
         } else if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
@@ -344,6 +399,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 f4 h[NC];
                 layer_norm_plain(x[i], h);
                 fstamp();
+                if constexpr (BF3) {
+                    u32x4 hb[3], hc[3];
+                    split_h3(h, hb, hc);
+                    u32x4 a0[2][3], a2[2][3];
+                    w1_load3(0, a0[0], a2[0]);
+#pragma unroll
+                    for (int t = 0; t < 3 * NC; ++t) {
+                        if (t + 1 < 3 * NC) w1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                        const int ot = t % NC;
+                        f4 r;
+                        if (t < 2 * NC) {
+                            const f4 bias = ld4(S + S_BQKV + 16 * t + 4 * q);
+                            __builtin_amdgcn_sched_barrier(0);
+                            r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias);
+                        } else {
+                            const f4 bias = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            r = tile48(std::true_type{}, a0[t & 1], a2[t & 1], hb, hc, bias);
+                        }
+                        if (t < NC) qr[i][ot] = r;
+                        else if (t < 2 * NC) Kimg[(T * NC + ot) * 64 + lane] = r;
+                        else Vimg[(ot * NT + T) * 64 + lane] = r;
+                        if (z_tile && zcache_mode == 1) zc[t * 64] = r;
+                        if (t == 2 * NC - 1) fstamp();
+                    }
+                } else {
                 {   // q and k: 6 independent chains, rows = features, cols = tokens (B = h shared)
                     f4 acc[2 * NC];
 #pragma unroll
@@ -378,10 +459,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         if (z_tile && zcache_mode == 1) zc[(2 * NC + ot) * 64] = acc[ot];
                     }
                 }
+                }
             }
         }
         if constexpr (BAL) {
-            if (w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
+            if (BF3 && w >= NOWN && g < 3) {
+                f4 h[NC];
+                layer_norm_plain(x4, h);
+                u32x4 hb[3], hc[3];
+                split_h3(h, hb, hc);
+                u32x4 a0[NC][3], a2[NC][3];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) w1_load3(NC * g + j, a0[j], a2[j]);
+                f4 r[NC];
+                if (g < 2) {
+                    f4 bias[NC];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) bias[j] = ld4(S + S_BQKV + 16 * (g * NC + j) + 4 * q);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) r[j] = tile48(std::false_type{}, a0[j], a2[j], hb, hc, bias[j]);
+                    f4* dst = g == 0 ? Qg : Kimg + GT * NC * 64;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) dst[j * 64 + lane] = r[j];
+                } else {
+                    f4 bias[NC];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) bias[j] = splat4(S[S_BQKV + 2 * C + 16 * j + tok]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) r[j] = tile48(std::true_type{}, a0[j], a2[j], hb, hc, bias[j]);
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) Vimg[(j * NT + GT) * 64 + lane] = r[j];
+                }
+            } else if (w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
                 f4 h[NC];
                 layer_norm_plain(x4, h);
                 f4 acc[NC];
@@ -656,42 +767,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         // (two independent accumulator chains; 12 MFMAs per tile: six terms on chunk pair (0, 1), six on chunk 2 with a zero
         // upper half), the next unit's weight pieces requested ahead, GELU + the split of the previous unit under the current
         // unit's MFMAs.  Unit u's two hidden tiles ARE fc2's chunk pair u, so the split results are fc2's B operands as they stand.
-        using vt3::u32x2;
-        using vt3::u32x4;
-        // the images' per-lane addresses are built from a fresh copy of the lane index in every block: as invariants of the block
-        // loop hipcc computed ~38 of them up front and spilled them (reloads wait on vmcnt, i.e. on the weight staging in flight)
-        int lane3 = lane;
-        if constexpr (BF3) asm volatile("" : "+v"(lane3));
-        const u32x4* const Wa3 = reinterpret_cast<const u32x4*>(Wa);
-        const u32x2* const Wa3h = reinterpret_cast<const u32x2*>(Wa);
-        const u32x4* const Wb3 = reinterpret_cast<const u32x4*>(Wb);
-        const u32x4* const Wk3 = reinterpret_cast<const u32x4*>(Kimg);
-        auto w1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {       // fc1 pieces of output tile t: chunk pair 0, chunk 2
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                a0[pc] = Wa3[t * W3_FC1_OT16 + pc * 64 + lane3];
-                const u32x2 v = Wa3h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
-                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
-            }
-        };
-        auto w2_load3 = [&](int p, u32x4 (&a)[NC][3]) {                     // fc2 pieces of chunk pair p, all three output tiles
-#pragma unroll
-            for (int ot = 0; ot < NC; ++ot)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    a[ot][pc] = ot < 2 ? Wb3[((ot * (NH / 2) + p) * 3 + pc) * 64 + lane3] : Wk3[(p * 3 + pc) * 64 + lane3];
-        };
-        auto split_h3 = [&](const f4 (&h)[NC], u32x4 (&hb)[3], u32x4 (&hc)[3]) {       // LN2's output as fc1's B operands
-            u32x2 a[3], b2[3], c[3];
-            vt3::split3(h[0], a[0], a[1], a[2]);
-            vt3::split3(h[1], b2[0], b2[1], b2[2]);
-            vt3::split3(h[2], c[0], c[1], c[2]);
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                hb[pc] = u32x4{a[pc].x, a[pc].y, b2[pc].x, b2[pc].y};
-                hc[pc] = u32x4{c[pc].x, c[pc].y, 0u, 0u};
-            }
-        };
         // N chains x 12 MFMAs: the small terms of both K steps first, then the large ones
         auto fc1_terms3 = [&](auto nc, const u32x4 (*a0)[3], const u32x4 (*a2)[3], const u32x4 (&hb)[3], const u32x4 (&hc)[3], f4* acc) {
             constexpr int N = decltype(nc)::value;
@@ -846,7 +921,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
                 stamp();            // fc1 done
             barrier_publish<true>();    // fc2 weights landed; buffer A free
-            if (blk + 1 < nblocks) stage_tiles(Wa, P + BLOCK_STRIDE + O_WQKV, QKV_TILES, w, NW, lane);   // next block's qkv
+            if (blk + 1 < nblocks) stage_tiles(Wa, P3 + BLOCK3_STRIDE + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);   // next block's qkv
             stamp();
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -992,17 +1067,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     stamp();
     // ---- epilogue: optional residual dump; final LayerNorm on the search tokens ----------------
     const float* PF = Sp + depth_total * SMALL_STRIDE;   // norm.weight, norm.bias
+    // BF3 (at the register cap): the output addresses are built here from a fresh copy of the lane index, not kept across the block loop
+    int lane_e = lane_k;
+    if constexpr (BF3) asm volatile("" : "+v"(lane_e));
+    const int tok_e = lane_e & 15, q_e = lane_e >> 4;
     const int Lx = L - len_z;
     if constexpr (BAL) {
         if (g == 0) {
             if (resid != nullptr) {
-                float* dst = resid + ((size_t)b * L + 16 * GT + tok) * C + 4 * q;
+                float* dst = resid + ((size_t)b * L + 16 * GT + tok_e) * C + 4 * q_e;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) st4(dst + 16 * c, x4[c]);
             }
             f4 h[NC];
-            layer_norm_img(x4, h, PF, PF + C, q);
-            float* dst = feat + ((size_t)b * Lx + (16 * GT - len_z) + tok) * C + 4 * q;
+            layer_norm_img(x4, h, PF, PF + C, q_e);
+            float* dst = feat + ((size_t)b * Lx + (16 * GT - len_z) + tok_e) * C + 4 * q_e;
 #pragma unroll
             for (int c = 0; c < NC; ++c) st4(dst + 16 * c, h[c]);
         }
@@ -1012,14 +1091,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         const int T = w + NW * i;
         if (T < NOWN) {
             if (resid != nullptr) {
-                float* dst = resid + ((size_t)b * L + 16 * T + tok) * C + 4 * q;
+                float* dst = resid + ((size_t)b * L + 16 * T + tok_e) * C + 4 * q_e;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) st4(dst + 16 * c, x[i][c]);
             }
             if (16 * T >= len_z) {   // len_z is a multiple of 16 for both supported geometries
                 f4 h[NC];
-                layer_norm_img(x[i], h, PF, PF + C, q);
-                float* dst = feat + ((size_t)b * Lx + (16 * T - len_z) + tok) * C + 4 * q;
+                layer_norm_img(x[i], h, PF, PF + C, q_e);
+                float* dst = feat + ((size_t)b * Lx + (16 * T - len_z) + tok_e) * C + 4 * q_e;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) st4(dst + 16 * c, h[c]);
             }
