@@ -105,6 +105,7 @@ struct vt_model {
     int stem_stream = -1;  // stem_stream_kernel (all four layers of a frame streamed band by band through one workgroup) instead of
                            // stem_pipe + stem_b (G256) / stem_fused (G128); auto: G256 B > 176 (fp32 build)
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
+    int blocks_bf3_g256 = 1;   // the same switch at G256 (MLP only, weights from L2)
     int blocks_bf3 = 1;    // VT_BLOCKS_BF3: the G128 frame form's MLP as exact three-piece bf16 products (0 = fp32 MFMA)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
@@ -529,6 +530,11 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
             return m->blocks_wlds ? launch_blocks<5, 5, 1, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                                   : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
+#ifndef VT_F16
+            if (m->blocks_bal && m->blocks_bf3_g256)
+                return zc ? launch_blocks<20, 8, 3, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                          : launch_blocks<20, 8, 3, false, false, false, true>(m, st, tokens, B, nblocks, feat, resid, zc);
+#endif
             if (m->blocks_bal) return zc ? launch_blocks<20, 8, 3, false, false, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                                          : launch_blocks<20, 8, 3, false>(m, st, tokens, B, nblocks, feat, resid, zc);
             return launch_blocks<20, 4, 5, false>(m, st, tokens, B, nblocks, feat, resid, zc);
@@ -823,6 +829,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     m->blocks_bf3 = env_int("VT_BLOCKS_BF3", 1);
+    m->blocks_bf3_g256 = m->blocks_bf3;
     // the BF3 form's staging buffers are 18 KiB larger: beyond depth 8 its small parameters no longer fit beside them -> fp32 form
     if (blocks_lds_bytes(5, true, true, cfg->depth, true) > LDS_PER_CU) m->blocks_bf3 = 0;
     m->stem_fused = env_int("VT_STEM_FUSED", -1);
@@ -882,6 +889,14 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
+#ifndef VT_F16
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
+#endif
 
         (void)small_bytes;
         if (e == hipSuccess)

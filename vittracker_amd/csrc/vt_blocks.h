@@ -233,7 +233,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                                                          int zcache_mode,     // 0: off, 1: compute and store, 2: load instead of computing
                                                          const float* __restrict__ params3) {   // BF3: the MLP's three-piece images, BLOCK3_STRIDE per block
     static_assert(NW * TPW >= NT, "tiles must be covered");
-    static_assert(!BF3 || (BAL && 2 * NT * NC >= W3_FC2_TILES - WBUF_TILES), "BF3: written for the balanced frame form; fc2's third output tile is staged in the K / V area");
+    // BF3L: the LDS-staged form (G128 balanced frame form: qkv + MLP); BF3G: weights from L2 as in every !WLDS form (G256: MLP only)
+    constexpr bool BF3L = BF3 && WLDS, BF3G = BF3 && !WLDS;
+    static_assert(!BF3L || (BAL && 2 * NT * NC >= W3_FC2_TILES - WBUF_TILES), "BF3 with staging: written for the balanced frame form; fc2's third output tile is staged in the K / V area");
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
     constexpr int L = NT * 16;
     constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]
     f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
     f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
-    constexpr int WA_TILES = BF3 ? W3_FC1_TILES : WBUF_TILES;      // BF3: fc1's three-piece image is 54 KiB
+    constexpr int WA_TILES = BF3L ? W3_FC1_TILES : WBUF_TILES;      // BF3: fc1's three-piece image is 54 KiB
     f4* Wb = Wa + WA_TILES * 64;                           // WLDS: [36][64] staging buffer B (BF3: fc2's output tiles 0 and 1; tile 2 goes to the K / V area, free during the MLP)
     float* Sp = reinterpret_cast<float*>(WLDS ? Wb + WBUF_TILES * 64 : Wa);   // small parameters, small_floats(depth)
     // BAL: guest exchange areas
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     };
     auto fstamp = [&]() { if (fine) stamp(); };     // per-stage stamps (VT_DBG_STAMPS=2)
     stamp();
-    if constexpr (BF3) stage_tiles(Wa, params3 + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);
+    if constexpr (BF3L) stage_tiles(Wa, params3 + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);
     else if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
     for (int i = threadIdx.x; 4 * i < small_floats(depth_total); i += NW * 64)
         st4(Sp + 4 * i, ld4(params + small_src(4 * i, depth_total)));
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
             return accA + accB;
         };
-        if constexpr (BF3) {
+        if constexpr (BF3L) {
             stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane);
         } else if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
 
@@ -402,11 +404,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 if constexpr (BF3) {
                     u32x4 hb[3], hc[3];
                     split_h3(h, hb, hc);
+                    // qkv pieces of output tile t: from the staging buffer (BF3L) or straight from L2 (BF3G), the next tile's in flight
+                    const u32x4* const Gq = reinterpret_cast<const u32x4*>(P3) + (W3_FC1_TILES + W3_FC2_TILES) * 64;
+                    const u32x2* const Gqh = reinterpret_cast<const u32x2*>(Gq);
+                    auto wq_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {
+                        if constexpr (BF3L) w1_load3(t, a0, a2);
+                        else {
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                a0[pc] = Gq[t * W3_FC1_OT16 + pc * 64 + lane3];
+                                const u32x2 v = Gqh[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+                            }
+                        }
+                    };
                     u32x4 a0[2][3], a2[2][3];
-                    w1_load3(0, a0[0], a2[0]);
+                    wq_load3(0, a0[0], a2[0]);
 #pragma unroll
                     for (int t = 0; t < 3 * NC; ++t) {
-                        if (t + 1 < 3 * NC) w1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                        if (t + 1 < 3 * NC) wq_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
                         const int ot = t % NC;
                         f4 r;
                         if (t < 2 * NC) {
@@ -463,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         if constexpr (BAL) {
-            if (BF3 && w >= NOWN && g < 3) {
+            if (BF3L && w >= NOWN && g < 3) {
                 f4 h[NC];
                 layer_norm_plain(x4, h);
                 u32x4 hb[3], hc[3];
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         stamp();            // QKV done
         barrier_publish<WLDS>();    // K/V published; proj weights landed; buffer A free
         stamp();
-        if constexpr (BF3) {
+        if constexpr (BF3L) {
             stage_tiles(Wa, P3, W3_FC1_TILES, w, NW, lane);
         } else if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
@@ -697,7 +713,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         stamp();            // attention + proj done
         barrier_publish<WLDS>();    // K/V and buffer B free; fc1 weights landed
         stamp();
-        if constexpr (BF3) {
+        if constexpr (BF3L) {
             stage_tiles(Wb, P3 + W3_FC1_TILES * 256, WBUF_TILES, w, NW, lane);                                          // fc2, output tiles 0 and 1
             stage_tiles(Kimg, P3 + (W3_FC1_TILES + WBUF_TILES) * 256, W3_FC2_TILES - WBUF_TILES, w, NW, lane);           // output tile 2
         } else if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 if (p == 1 || p == 3) fstamp();
             }
         };
-        if constexpr (BF3) {
+        if constexpr (BF3L) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
@@ -1019,7 +1035,70 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+                if (BF3G && T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+                    // BF3G: the same per-tile MLP as exact three-piece bf16 products, weight pieces straight from L2 (vt_bf3.h; images
+                    // as in the staged form): fc1 one hidden tile per step, the pieces of the tile after next in flight; GELU + split
+                    // once per hidden tile; fc2 per chunk pair with the next pair's pieces in flight
+                    const u32x4* const G1 = reinterpret_cast<const u32x4*>(P3);
+                    const u32x2* const G1h = reinterpret_cast<const u32x2*>(P3);
+                    const u32x4* const G2 = G1 + W3_FC1_TILES * 64;
+                    auto g1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            a0[pc] = G1[t * W3_FC1_OT16 + pc * 64 + lane3];
+                            const u32x2 v = G1h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                            a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+                        }
+                    };
+                    f4 h[NC];
+                    layer_norm_plain(x[i], h);
+                    u32x4 hb[3], hc[3];
+                    split_h3(h, hb, hc);
+                    u32x4 hq3[NH / 2][3];
+                    {
+                        u32x4 a0[2][3], a2[2][3];
+                        g1_load3(0, a0[0], a2[0]);
+                        u32x2 pl[3];
+#pragma unroll
+                        for (int t = 0; t < NH; ++t) {
+                            if (t + 1 < NH) g1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                            const f4 bias = ld4(S + S_B1 + 16 * t + 4 * q);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const f4 r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias);
+                            u32x2 pc3[3];
+                            vt3::split3(gelu4(r), pc3[0], pc3[1], pc3[2]);
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) {
+                                if (t & 1) hq3[t >> 1][pc] = u32x4{pl[pc].x, pl[pc].y, pc3[pc].x, pc3[pc].y};
+                                else pl[pc] = pc3[pc];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
+                    {
+                        constexpr int NP = NH / 2;
+                        constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+                        // 18 steps of (chunk pair p, output tile ot): 6 MFMAs on x[ot] each, the pieces of the step three ahead in flight
+                        auto g2_load3 = [&](int st, u32x4 (&a)[3]) {
+                            const int p = st / NC, ot = st - NC * p;
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) a[pc] = G2[((ot * NP + p) * 3 + pc) * 64 + lane3];
+                        };
+                        constexpr int NS = NP * NC, AHEAD = 3;
+                        u32x4 a[AHEAD + 1][3];
+#pragma unroll
+                        for (int st = 0; st < AHEAD; ++st) g2_load3(st, a[st]);
+#pragma unroll
+                        for (int st = 0; st < NS; ++st) {
+                            if (st + AHEAD < NS) g2_load3(st + AHEAD, a[(st + AHEAD) % (AHEAD + 1)]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int p = st / NC, ot = st - NC * p;
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) x[i][ot] = vt3::mma(a[st % (AHEAD + 1)][TW[e]], hq3[p][TX[e]], x[i][ot]);
+                        }
+                    }
+                } else if (T < NT && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                     f4 h[NC];
                     layer_norm_plain(x[i], h);
                     f4 hd[NH];
