@@ -10,6 +10,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -143,3 +144,46 @@ def test_vitb_graph_chains_match_eager(chains):
     env = dict(os.environ, VT_GRAPH_CHAINS=chains)
     r = subprocess.run([sys.executable, "-c", VITB_CHAINS_CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+
+
+# The bf16-split forms (vt_bf3.h: qkv + MLP of the frame-form block kernels, the F = 8 head's towers) multiply the same fp32 operands
+# as the fp32-MFMA forms they replace; on a full batch of random crops -- every frame-form kernel, 256 frames instead of a fixture's
+# 2-5 -- the two must agree to the fp32 noise floor of the net (a few 1e-6 on the maps), far inside the 1e-4 / 1e-5 the golden
+# tests hold either of them to.  This is the direct statement that the split is a faster way to issue fp32 products, not a
+# precision change.
+SPLIT_CODE = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from vittracker_amd import native, synth
+tz, tx, B = %(tz)d, %(tx)d, %(B)d
+m = native.Model(tz, tx, max_batch=B)
+m.load_state_dict(synth.synth_state_dict(3, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2))
+z, x = synth.synth_inputs(17, B, tz, tx)
+out = m.forward(torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda())
+torch.cuda.synchronize()
+np.savez(%(path)r, score=out.score_map.cpu().numpy(), size=out.size_map.cpu().numpy(), offset=out.offset_map.cpu().numpy(),
+         pred=out.pred_boxes.cpu().numpy())
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_bf16_split_forms_agree_with_fp32_mfma_forms_on_a_full_batch(geom, tmp_path):
+    tz, tx = {"G128": (64, 128), "G256": (128, 256)}[geom]
+    res = {}
+    for name, env in (("split", {}), ("fp32", {"VT_BLOCKS_BF3": "0", "VT_HEAD_BF3": "0"})):
+        path = str(tmp_path / f"{name}.npz")
+        code = SPLIT_CODE % {"root": ROOT, "tz": tz, "tx": tx, "B": 256, "path": path}
+        e = {k: v for k, v in os.environ.items() if k not in ("VT_BLOCKS_BF3", "VT_HEAD_BF3")}
+        r = subprocess.run([sys.executable, "-c", code], env=dict(e, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+        res[name] = np.load(path)
+    a, b = res["split"], res["fp32"]
+    assert not np.array_equal(a["score"], b["score"]), "the switch selected the same kernels twice"
+    # maps: sigmoid / clamp outputs in [1e-4, 1] and raw offsets of O(1); boxes: a grid cell index + offset, / 8 or / 16
+    for k, tol in (("score", 1e-5), ("size", 1e-5), ("offset", 2e-5)):
+        assert np.abs(a[k] - b[k]).max() <= tol, (k, float(np.abs(a[k] - b[k]).max()))
+    # a box moves by more than the noise only where the two runs pick different argmax cells of near-tied scores
+    same = np.abs(a["pred"] - b["pred"]).max(axis=1) <= 1e-5
+    assert same.mean() >= 0.99, float(same.mean())
+
