@@ -1,7 +1,8 @@
 // vt_bf3.h -- fp32 products on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces, x = h + m + l
 // (8 mantissa bits each, by truncation: every residual is an exact fp32 subtraction), and a product a b is the six terms
-// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16; what is dropped (ml, lm, ll) is below 2^-23 of
-// |a b|, the rounding of an fp32 MFMA itself (tools/src/probe_bf3.hip, on the hardware: max error / sum |a b| 2.6e-7 against
+// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16; what is dropped (ml, lm, ll) is about ONE fp32
+// rounding per product -- 2^-24.6 of |a b| on average, below 2^-21 for any operands (tests/test_bf3_arithmetic.py) -- and in a sum it
+// disappears in the accumulator's own fp32 rounding (tools/src/probe_bf3.hip, on the hardware: max error / sum |a b| 2.6e-7 against
 // 3.0e-7 for v_mfma_f32_16x16x4_f32).  Six 16 x 16 x 32 instructions cover EIGHT times the K of a 16 x 16 x 4 fp32 MFMA in
 // 6 x 16 cycles against 8 x 32, and VALU work issues beside them.  Shared by vt_head3.h (towers) and vt_blocks.h (MLP).
 //

@@ -1,7 +1,7 @@
 // vt_head3.h -- the CENTER head's towers (F = 8) on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is split EXACTLY
 // into three bf16 pieces, x = h + m + l (8 mantissa bits each, by truncation), and a product a b is the six terms
-// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- what is dropped (ml, lm, ll) is below 2^-23 of
-// |a b|, the error of an fp32 MFMA's own rounding (tools/src/probe_bf3.hip: max error / sum |a b| over random 16 x 16 x 16
+// hh + hm + mh + hl + lh + mm accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- what is dropped (ml, lm, ll) is about one fp32
+// rounding per product (2^-24.6 of |a b| on average, < 2^-21 always: vt_bf3.h) and vanishes in the accumulator's own (tools/src/probe_bf3.hip: max error / sum |a b| over random 16 x 16 x 16
 // products 2.6e-7 against 3.0e-7 for v_mfma_f32_16x16x4_f32).  Same results contract as vt_head.h (reference:
 // lib/models/layers/head.py:130-201), same maps, same weights -- folded BatchNorm, fp32 bias, ReLU, conv5 and the decode are
 // untouched fp32 code.
