@@ -47,8 +47,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--idle", type=float, default=2.0)
     ap.add_argument("--window", type=float, default=0.5)
+    ap.add_argument("--lib", default="", help="another build of the library (build_variants/*.so)")
     a = ap.parse_args()
     import bench
+    if a.lib:
+        from vittracker_amd import native
+        native.LIB_PATH = os.path.abspath(a.lib)
     sens = sensors()
     print("sensors:", json.dumps(sens))
     r = bench.Runner(a.geom, a.B, steps_per_graph=4)

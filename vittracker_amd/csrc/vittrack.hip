@@ -67,6 +67,7 @@ struct vt_model {
     bool weights_loaded = false;
     // parameters on the device
     DevBuf stem_w[4], stem_b[4];     // folded, [group][tap][cin][OCG] / [cout]
+    DevBuf stem_w3b;                 // layer 3 as three-piece bf16 images (stem_fused, fp32 build)
     DevBuf stem_w2k;                 // layer 2 again as [tap][input-channel quad][16 output channels][4] for the 4-block f32 MFMA
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
@@ -397,7 +398,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
                                m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p,
-                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p);
+                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p, m->stem_w3b.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_fused_kernel<0, true>);
@@ -945,6 +946,7 @@ void vt_destroy(vt_model* m) {
     if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
+    m->stem_w3b.release();
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->blocks3, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
@@ -995,6 +997,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
                         for (int ic = 0; ic < STEM_CH[1]; ++ic)
                             k[(((size_t)tap * 2 + ic / 4) * 16 + oc) * 4 + ic % 4] = (float)w[((size_t)oc * STEM_CH[1] + ic) * 9 + tap];
                 if ((rc = upload(m->stem_w2k, k))) return rc;
+            }
+            if (i == 2) {   // layer 3 as three-piece bf16 images (vt_stem_fused.h, fp32 build): [out tile 2][pair 4][piece 3][64][8 bf16]
+                std::vector<uint16_t> img3((size_t)2 * 4 * 3 * 64 * 8, 0);
+                pack_conv_image3(w, STEM_CH[3], STEM_CH[2], img3.data());
+                std::vector<float> as_f(img3.size() / 2);
+                std::memcpy(as_f.data(), img3.data(), img3.size() * 2);
+                if ((rc = upload(m->stem_w3b, as_f))) return rc;
             }
         }
     }

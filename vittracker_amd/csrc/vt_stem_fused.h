@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "vt_common.h"
+#include "vt_bf3.h"
 #include "vt_conv.h"
 #include "vt_stem.h"
 
@@ -55,6 +56,10 @@ struct FusedGeo {                       // TX = 128, TZ = 64
     static constexpr int LDS_F4 = 2 * RING + 3 * NPIX2X + 3 * NPIX2Z + CONST_F4 + OFFTAB_F4;
     static constexpr int LDS_BYTES = LDS_F4 * 16;                          // 144,768
     static_assert(6 * NPIX3X + 6 * NPIX3Z <= 2 * RING, "layer-3 maps must fit in the rings");
+    // fp32 build: layer 3's three-piece weight image (24 KiB), staged behind the layer-3 maps in group B's ring during the pipeline's
+    // last interval (that ring dies an interval early and its group idles)
+    static constexpr int W3L_OFF = 6 * NPIX3X + 6 * NPIX3Z, W3L_TILES = 2 * 4 * 3;
+    static_assert(W3L_OFF >= RING + 0 && W3L_OFF + W3L_TILES * 64 <= 2 * RING, "layer-3 weight pieces must lie inside group B's ring");
     static_assert((2 * R2X) * (TX / 4) == 512 && (2 * R2Z) * (TZ / 4) == 512, "one pixel pair per thread of a group");
 };
 
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w3img, const float* __restrict__ b3, const float* __restrict__ w4img, const float* __restrict__ b4,
     const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip_arg,
     unsigned long long* __restrict__ stamps,       // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
-    const float* __restrict__ w2k) {               // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
+    const float* __restrict__ w2k,                 // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
+    const float* __restrict__ w3b) {               // layer-3 weights as three-piece bf16 images [out tile 2][chunk pair 4][piece 3][64 lanes][8 bf16] (f32 build)
     using G = FusedGeo;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
     const int skip = DIAG ? skip_arg : 0;
@@ -345,11 +351,25 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     // Both sequences execute the same six barriers.
     // layer-3 / layer-4 weights of this wave are requested while the pipeline's last interval runs /
     // while layer 3 runs, so their L2 round trips are not exposed
-    constexpr int NCH3 = 7, NCH4 = 14;
+    constexpr int NCH4 = 14;
+#ifdef VT_F16
+    constexpr int NCH3 = 7;
     const int ot3 = wave & 1;
     f4 w3a[NCH3][1];
     auto load_w3 = [&]() { vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a); };
-    if (skip & 1) load_w3();
+#else
+    // layer 3 runs as three-piece bf16 products (vt_bf3.h): every wave needs the WHOLE image, so it goes through LDS.  Group B's
+    // eight waves stage it (three LDS-DMA pieces each) in the interval in which they have nothing else to do.
+    auto load_w3 = [&]() {
+        if (grp == 1) {
+            for (int t = gw; t < G::W3L_TILES; t += 8)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3b + (size_t)t * 256 + lane * 4),
+                                                 (__attribute__((address_space(3))) void*)(lds + G::W3L_OFF + t * 64), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+#endif
+    if (skip & 1) { load_w3(); __syncthreads(); }
     if (!(skip & 1)) {
         const bool l2 = !(skip & 2);
         // zmode: a crop that is not wanted keeps its barriers and drops its work (all conditions are wave-uniform)
@@ -397,6 +417,71 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             else if (e < 43) m3z[plane * G::NPIX3Z + (e - 34)] = splat4(0.f);
             else m3z[plane * G::NPIX3Z + (e - 43) * 9 + 4] = splat4(0.f);
         }
+#ifndef VT_F16
+        // fp32 build: layer 3 as exact three-piece bf16 products.  The layer-2 maps stay fp32 (pre-split maps do not fit), so a B
+        // operand is split where it is read -- which pays only if one split feeds BOTH output tiles: a wave takes one pixel tile
+        // (x: map row `wave`; z: waves 0-3, 16 pixels each) and both tiles; 7 splits + 48 bf16 MFMAs per unit instead of 56 fp32
+        // MFMAs per (unit, output tile), and the four waves of a SIMD overlap each other's splits and MFMAs.  Chunk 7 does not
+        // exist (27 quads): its half of the last pair carries zero weights and re-uses chunk 6's pieces.
+        if (!(skip & 4)) {
+            using vt3::u32x2;
+            using vt3::u32x4;
+            const u32x4* const W3L = reinterpret_cast<const u32x4*>(lds + G::W3L_OFF);
+            constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            auto unit3 = [&](const f4* map2, int base, const int* tab, f4 (&acc)[2]) {
+                int o3[G::OFF3];
+                {
+                    const int4* tp = reinterpret_cast<const int4*>(tab);
+                    const int4 a = tp[0], bq = tp[1];
+                    o3[0] = a.x; o3[1] = a.y; o3[2] = a.z; o3[3] = a.w; o3[4] = bq.x; o3[5] = bq.y; o3[6] = bq.z; o3[7] = bq.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    u32x4 A[2][3];
+#pragma unroll
+                    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) A[ot][pc] = W3L[((ot * 4 + p) * 3 + pc) * 64 + lane];
+                    u32x2 lo[3], hi[3];
+                    vt3::split3(map2[o3[2 * p] + base], lo[0], lo[1], lo[2]);
+                    if (p < 3) vt3::split3(map2[o3[2 * p + 1] + base], hi[0], hi[1], hi[2]);
+                    u32x4 B[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) B[pc] = p < 3 ? u32x4{lo[pc].x, lo[pc].y, hi[pc].x, hi[pc].y} : u32x4{lo[pc].x, lo[pc].y, lo[pc].x, lo[pc].y};
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) acc[ot] = vt3::mma(A[ot][TW[e]], B[TX[e]], acc[ot]);
+                }
+            };
+            const f4 bias0 = ld4(cb3 + 4 * q), bias1 = ld4(cb3 + 16 + 4 * q);
+            if (do_x) {   // search: pixel tile = row `wave` of the 16 x 16 map
+                constexpr int P2 = G::TX / 4 + 1, P3 = G::TX / 8 + 1, H3 = G::TX / 16;
+                f4 acc[2] = {bias0, bias1};
+                unit3(m2, 2 * wave * P2 + px, otab + q * G::OFF3, acc);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    if (16 * ot + 4 * q < 24) {
+                        f4 r = acc[ot];
+                        r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                        m3x[(4 * ot + q) * G::NPIX3X + (wave + 1) * P3 + ((px & 1) ? H3 + 1 + (px >> 1) : (px >> 1))] = r;
+                    }
+            }
+            if (wave < 4 && do_z) {   // template: 4 pixel tiles of the 8 x 8 map
+                constexpr int P2 = G::TZ / 4 + 1, P3 = G::TZ / 8 + 1, H3 = G::TZ / 16;
+                const int op = 16 * wave + px, y = op >> 3, x = op & 7;
+                f4 acc[2] = {bias0, bias1};
+                unit3(m2 + M2Z_OFF, 2 * y * P2 + x, otab + 4 * G::OFF3 + q * G::OFF3, acc);
+#pragma unroll
+                for (int ot = 0; ot < 2; ++ot)
+                    if (16 * ot + 4 * q < 24) {
+                        f4 r = acc[ot];
+                        r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
+                        m3z[(4 * ot + q) * G::NPIX3Z + (y + 1) * P3 + ((x & 1) ? H3 + 1 + (x >> 1) : (x >> 1))] = r;
+                    }
+            }
+        }
+#else
         const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
         if (!(skip & 4)) {
             if (do_x) {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
@@ -445,6 +530,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                 }
             }
         }
+#endif
     }
     stamp();
     __syncthreads();
