@@ -163,10 +163,11 @@ __device__ __forceinline__ void barrier_publish() {
 }
 
 #ifndef VT_BLK_NOSTAGE
-#define VT_BLK_NOSTAGE 0       // timing experiment only (wrong results): 1 = no weight staging at all
-#endif
-__device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ src, int ntiles, int w, int nw, int lane) {
-    if (VT_BLK_NOSTAGE) return;
+#define VT_BLK_NOSTAGE 0       // timing experiments only (wrong results): 1 = no weight staging at all -- the MFMAs then run on whatever the LDS
+#endif                         // held, mostly zeros, cooler and at higher clocks: NOT a measure of what staging costs; 2 (BF3L form) = staging in
+                               // block 0 only, its valid weights re-used by the later blocks: that is (38.0 against 38.9 us: ~1.3 us for three blocks)
+__device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ src, int ntiles, int w, int nw, int lane, bool first_block = true) {
+    if (VT_BLK_NOSTAGE == 1 || (VT_BLK_NOSTAGE == 2 && !first_block)) return;
     for (int t = w; t < ntiles; t += nw)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)t * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(dst + t * 64), 16, 0, 0);
@@ -322,8 +323,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         auto w_fc2 = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_W2, t, lane); };
         // BF3 staging: the same four bursts per block as the fp32 form, issued by all eight waves at the start of the phase before the
         // one that reads them (fc1 54 KiB -> Wa during attention; fc2 36 KiB -> Wb + 18 KiB -> the K / V area during the fc1 phase).
-        // A burst is not free for the waves that issue it -- with staging compiled out (VT_BLK_NOSTAGE) the BF3 kernel takes 36.4
-        // instead of 40.5 us, the fp32 one 41.4 instead of 43.5 -- but every other placement measured slower or equal.
+        // The bursts cost ~1.3 us per launch (VT_BLK_NOSTAGE = 2); every other placement measured slower or equal.
         const float* __restrict__ P3 = BF3 ? params3 + (size_t)blk * BLOCK3_STRIDE : nullptr;
         constexpr int PROJ_TILES = NC * NC;
         using vt3::u32x2;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             return accA + accB;
         };
         if constexpr (BF3L) {
-            stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane);
+            stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane, blk == 0);
         } else if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
 
         f4 qr[TPW][NC];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         barrier_publish<WLDS>();    // K/V published; proj weights landed; buffer A free
         stamp();
         if constexpr (BF3L) {
-            stage_tiles(Wa, P3, W3_FC1_TILES, w, NW, lane);
+            stage_tiles(Wa, P3, W3_FC1_TILES, w, NW, lane, blk == 0);
         } else if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
         // output, proj and MLP never reach the head (vit_dist.py:126 keeps the search rows only),
@@ -714,8 +714,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         barrier_publish<WLDS>();    // K/V and buffer B free; fc1 weights landed
         stamp();
         if constexpr (BF3L) {
-            stage_tiles(Wb, P3 + W3_FC1_TILES * 256, WBUF_TILES, w, NW, lane);                                          // fc2, output tiles 0 and 1
-            stage_tiles(Kimg, P3 + (W3_FC1_TILES + WBUF_TILES) * 256, W3_FC2_TILES - WBUF_TILES, w, NW, lane);           // output tile 2
+            stage_tiles(Wb, P3 + W3_FC1_TILES * 256, WBUF_TILES, w, NW, lane, blk == 0);                                          // fc2, output tiles 0 and 1
+            stage_tiles(Kimg, P3 + (W3_FC1_TILES + WBUF_TILES) * 256, W3_FC2_TILES - WBUF_TILES, w, NW, lane, blk == 0);           // output tile 2
         } else if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
         // ---- LN2 + MLP (residual add) ---------------------------------------------------------
         // fc1 -> GELU -> fc2 in three groups of HG = 4 hidden tiles, software-pipelined so GELU (VALU)
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
                 stamp();            // fc1 done
             barrier_publish<true>();    // fc2 weights landed; buffer A free
-            if (blk + 1 < nblocks) stage_tiles(Wa, P3 + BLOCK3_STRIDE + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);   // next block's qkv
+            if (blk + 1 < nblocks) stage_tiles(Wa, P3 + BLOCK3_STRIDE + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane, false);   // next block's qkv
             stamp();
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
