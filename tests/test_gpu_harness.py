@@ -112,3 +112,30 @@ def test_record_graph_form_is_as_fast_as_the_plain_form():
         plain.append(run([]))
         rec.append(run(["--record-graphs"]))
     assert abs(max(rec) / max(plain) - 1.0) < 0.03, (plain, rec)
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_two_shards_on_two_streams_equal_their_sequential_runs(geom):
+    """bench.py's default launch pattern (--streams 2): two models -- two independent shards of sequences, each with its own
+    workspaces and 4-step graph -- launched alternately on two HIP streams, so that kernels of both are resident on the chip at
+    the same time.  Every output of every step must be bit-identical to the same model run alone."""
+    import torch
+    import bench
+    B = 256 if geom == "G128" else 96
+    rs = [bench.Runner(geom, B, seed=5 + 11 * k, steps_per_graph=4) for k in range(2)]
+    want = []
+    for r in rs:                                   # alone, eager
+        out = r.model.forward(r.z, r.x)
+        torch.cuda.synchronize()
+        want.append({k: getattr(out, k).clone() for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")})
+    for rep in range(30):                          # interleaved, several launches in flight on each stream
+        for r in rs:
+            r.graph_s.launch(r.stream)
+    torch.cuda.synchronize()
+    for r, w in zip(rs, want):
+        for o in r.outs:                           # the four steps of the last graph launch
+            for k, v in w.items():
+                assert torch.equal(getattr(o, k), v), (geom, k)
+    assert not torch.equal(want[0]["score_map"], want[1]["score_map"])
+    for r in rs:
+        r.close()
