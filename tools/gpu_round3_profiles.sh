@@ -1,4 +1,6 @@
 #!/bin/bash
+# (kernel stats and counters are taken on ONE stream -- a kernel alone on the chip, which is what bench.py's roofline.avg_launch_us
+# times; the default bench line runs two shards on two streams, whose kernels overlap)
 # Round-3 evidence in one box session: rocprofv3 kernel stats (G128, G256, ViT-Base), PMC passes (G128, G256 -> summaries +
 # profiles/pmc_traffic.json; ViT-Base FETCH_SIZE / WRITE_SIZE -> per-step HBM bytes), default bench line.
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -6,7 +8,7 @@ O=$R/gpurun_out/r3prof; rm -rf $O; mkdir -p $O
 COMMIT=${1:-unknown}
 cd /tmp && export TMPDIR=/tmp
 for g in G128 G256; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$g -- python3 $R/bench.py --geom $g --steps 100 --warmup 20 --no-cpu --no-extra > $O/stats_$g.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$g -- python3 $R/bench.py --geom $g --steps 100 --warmup 20 --no-cpu --no-extra --streams 1 > $O/stats_$g.log 2>&1
   cp $O/stats_$g/*/*kernel_stats.csv $O/r3_$(echo $g | tr A-Z a-z)_kernel_stats.csv
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vitb -- python3 $R/tools/vitb_time.py > $O/stats_vitb.log 2>&1

@@ -16,7 +16,7 @@ SETS=(
 )
 i=0
 for s in "${SETS[@]}"; do
-  timeout 300 rocprofv3 --pmc $s --output-format csv -d "$R/$OUT/set$i" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-extra "$@" > "$R/$OUT/set$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $s --output-format csv -d "$R/$OUT/set$i" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-extra --streams 1 "$@" > "$R/$OUT/set$i.log" 2>&1
   i=$((i+1))
 done
 python3 "$R/tools/pmc_summary.py" "$R/$OUT" | tee "$R/$OUT/summary.txt"
