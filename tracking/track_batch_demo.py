@@ -69,6 +69,31 @@ def main():
         dt = time.time() - t0
         print(f"track_chunk, {n} frames per launch, frames on the device: {B * (a.frames // n) * n / dt:.0f} frames/s, "
               f"{dt / ((a.frames // n) * n) * 1e3:.3f} ms per frame")
+    # Two shards of B sequences, each a BatchedVitTracker of its own (own model workspaces, states and graphs) on its own stream,
+    # stepped alternately: the trackers run on the CURRENT stream, so two stream contexts are all it takes.  Kernels of the two
+    # shards overlap at their tails and nothing is left of the gap between graph launches.
+    bt2 = BatchedVitTracker(p, B)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    trackers = [bt, bt2]
+    with torch.cuda.stream(streams[1]):
+        bt2.initialize(frames[0], boxes)
+    torch.cuda.synchronize()
+    n = 4
+    chunk = dev[[i & 1 for i in range(n)]].contiguous()
+    for _ in range(3):
+        for t, st in zip(trackers, streams):
+            with torch.cuda.stream(st):
+                t.track_chunk(chunk, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for f in range(a.frames // n):
+        for t, st in zip(trackers, streams):
+            with torch.cuda.stream(st):
+                out = t.track_chunk(chunk, sync=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"two shards of {B} sequences on two streams, track_chunk {n} frames per launch: {2 * B * (a.frames // n) * n / dt:.0f} frames/s, "
+          f"{dt / (2 * (a.frames // n) * n) * 1e3:.3f} ms per frame of one shard")
 
 
 if __name__ == "__main__":
