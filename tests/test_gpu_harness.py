@@ -44,6 +44,11 @@ def test_sequential_and_batched_runs_write_identical_box_files(tmp_path, monkeyp
     run_dataset_batched(ds, tc, batch=4, frames_per_launch=3)     # 3 frames per graph launch: the same files again
     for s in ds:
         assert open(os.path.join(tc.results_dir, s.name + ".txt")).read() == open(os.path.join(tb.results_dir, s.name + ".txt")).read()
+    for shards, n in ((2, 1), (3, 2)):                            # sub-groups on their own streams (ShardedBatchedTracker): the same files again
+        tsd = _tracker(tmp_path / f"shards{shards}", monkeypatch)
+        run_dataset_batched(ds, tsd, batch=4, frames_per_launch=n, shards=shards)
+        for s in ds:
+            assert open(os.path.join(tsd.results_dir, s.name + ".txt")).read() == open(os.path.join(tb.results_dir, s.name + ".txt")).read()
     # the target really is tracked on these textures? no: weights are synthetic -- only consistency is asserted
 
 
@@ -139,3 +144,33 @@ def test_two_shards_on_two_streams_equal_their_sequential_runs(geom):
     assert not torch.equal(want[0]["score_map"], want[1]["score_map"])
     for r in rs:
         r.close()
+
+
+def test_sharded_batched_tracker_equals_one_batched_tracker():
+    """ShardedBatchedTracker: B sequences as two / three groups on their own streams give, sequence by sequence and frame by frame,
+    exactly what one BatchedVitTracker of B sequences gives (device frames, host frames, chunks)."""
+    import torch
+    from vittracker_amd.batched import BatchedVitTracker, ShardedBatchedTracker
+    from vittracker_amd.parameter import vit_dist as P
+    os.environ.setdefault("VITTRACK_PRJ_DIR", REPO)
+    p = P.parameters("vit_48_h32_g128")
+    p.allow_synthetic_weights = True
+    B, H, W = 10, 120, 160
+    rs = np.random.RandomState(3)
+    frames = rs.randint(0, 256, (7, B, H, W, 3)).astype(np.uint8)
+    boxes = np.stack([rs.uniform(20, 90, B), rs.uniform(20, 60, B), rs.uniform(15, 40, B), rs.uniform(15, 40, B)], 1)
+    one = BatchedVitTracker(p, B)
+    one.initialize(frames[0], boxes)
+    want = [one.track(frames[t])["target_bbox"].numpy().copy() for t in (1, 2)]
+    want += list(one.track_chunk(frames[3:6])["target_bbox"].numpy().copy())
+    want.append(one.track(torch.from_numpy(frames[6]).cuda())["target_bbox"].numpy().copy())
+    for shards in (2, 3):
+        sh = ShardedBatchedTracker(p, B, shards)
+        assert sum(sh.sizes) == B and len(sh.trackers) == shards
+        sh.initialize(frames[0], boxes)
+        got = [sh.track(frames[t])["target_bbox"].numpy().copy() for t in (1, 2)]
+        got += list(sh.track_chunk(frames[3:6])["target_bbox"].numpy().copy())
+        got.append(sh.track(torch.from_numpy(frames[6]).cuda())["target_bbox"].numpy().copy())
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(a, b)
+

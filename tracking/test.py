@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 
 def run_tracker(tracker_name, tracker_param, run_id=None, dataset_name="synthetic", sequence=None, debug=0, threads=0,
-                num_gpus=8, batch=0, synthetic_weights=False, frames_per_launch=1):
+                num_gpus=8, batch=0, synthetic_weights=False, frames_per_launch=1, shards=1):
     from vittracker_amd.evaluation import Tracker, get_dataset
     from vittracker_amd.evaluation.running import run_dataset, run_dataset_batched
     dataset = get_dataset(dataset_name)
@@ -36,7 +36,7 @@ def run_tracker(tracker_name, tracker_param, run_id=None, dataset_name="syntheti
         if world > 1:
             import torch
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        run_dataset_batched(dataset, tracker, batch=batch, rank=rank, world=world, frames_per_launch=frames_per_launch)
+        run_dataset_batched(dataset, tracker, batch=batch, rank=rank, world=world, frames_per_launch=frames_per_launch, shards=shards)
     else:
         run_dataset(dataset, [tracker], debug, threads, num_gpus=num_gpus)
 
@@ -52,6 +52,8 @@ def main():
     p.add_argument("--threads", type=int, default=0, help="Number of worker processes (0 = sequential).")
     p.add_argument("--num_gpus", type=int, default=8)
     p.add_argument("--batch", type=int, default=0, help="> 0: lock-step batches of this many sequences per GPU")
+    p.add_argument("--shards", type=int, default=1,
+                   help="with --batch: step a group's sequences as this many independent sub-groups on their own HIP streams (ShardedBatchedTracker)")
     p.add_argument("--frames_per_launch", type=int, default=1,
                    help="with --batch: frames read ahead and tracked per graph launch (BatchedVitTracker.track_chunk)")
     p.add_argument("--synthetic_weights", action="store_true", help="run on the seeded synthetic weights")
@@ -61,7 +63,7 @@ def main():
     except (TypeError, ValueError):
         seq = a.sequence
     run_tracker(a.tracker_name, a.tracker_param, a.runid, a.dataset_name, seq, a.debug, a.threads, a.num_gpus, a.batch,
-                a.synthetic_weights, a.frames_per_launch)
+                a.synthetic_weights, a.frames_per_launch, a.shards)
 
 
 if __name__ == "__main__":

@@ -74,12 +74,13 @@ def _groups(dataset, batch):
             yield hw, seqs[i:i + batch]
 
 
-def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=None, make_batched=None, frames_per_launch=1):
+def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=None, make_batched=None, frames_per_launch=1, shards=1):
     """Lock-step batched run of `tracker` (an evaluation.Tracker) over `dataset`.  Sequence s belongs to rank
     s % world.  Ragged lengths: a finished sequence keeps receiving its last frame (its extra outputs are dropped).
     Per-frame time written for a sequence = wall time of the lock-step step / live sequences in that step (amortised:
     there is no per-sequence call to time).  frames_per_launch > 1: that many frames are read ahead and tracked by one
-    graph launch (BatchedVitTracker.track_chunk; same boxes, the files come out identical).
+    graph launch (BatchedVitTracker.track_chunk; same boxes, the files come out identical).  shards > 1: a group's sequences
+    are stepped as that many independent sub-groups on their own streams (ShardedBatchedTracker; same boxes, identical files).
     Returns {seq.name: output dict} for this rank's sequences."""
     from ..parallel import shard_sequences
     mine = [dataset[i] for i in shard_sequences(len(dataset), rank, world)]
@@ -87,8 +88,8 @@ def run_dataset_batched(dataset, tracker, batch=256, rank=0, world=1, params=Non
     params = params or tracker.get_parameters()
     params.debug = 0
     if make_batched is None:
-        from ..batched import BatchedVitTracker
-        make_batched = BatchedVitTracker
+        from ..batched import BatchedVitTracker, ShardedBatchedTracker
+        make_batched = BatchedVitTracker if int(shards) <= 1 else (lambda p, B: ShardedBatchedTracker(p, B, int(shards)))
     # A sequence whose init box is too small to crop makes `sample_target` raise in the reference (processing_utils.py:33-34),
     # and `run_sequence` prints the error and skips THAT sequence (running.py:138-142): screened out here, per sequence, before
     # the lock-step groups are formed, so one bad box does not cost its whole group.
