@@ -122,6 +122,26 @@ def measure(a, variants=("f16_uncached", "f32_cached", "f32_uncached")):
     while time.perf_counter() - t0 < 0.35:
         s.run(40); torch.cuda.synchronize()
     elapsed = s.timed(frames, a.warmup)
+    # bench.py --streams 2 (the default): a second shard of B sequences with its own model workspaces, ring graph and stream; the two
+    # shards' ring graphs are launched alternately, `frames` frames of each shard's sequences
+    nshard, single = 1, None
+    if int(getattr(a, "streams", 1)) > 1 and frames % RING == 0:
+        s2 = Seq(geom, B, "f16", cached=True)
+        s2.check_cache_exact()
+
+        def both(nfr):
+            for _ in range(nfr // RING):
+                s.ring_graph.launch(s.s)
+                s2.ring_graph.launch(s2.s)
+        both(max(RING, (a.warmup // RING) * RING))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        both(frames)
+        torch.cuda.synchronize()
+        single = B * frames / elapsed
+        elapsed = (time.perf_counter() - t0) / 2          # per `frames` frames of ONE shard
+        nshard = 2
+        s2.close()
     s.close()
     macs = B0.macs_per_frame(*GEOMS[geom])
     value = B * frames / elapsed
@@ -132,9 +152,12 @@ def measure(a, variants=("f16_uncached", "f32_cached", "f32_uncached")):
                                    f"cache (template tokens + block-0 q,k,v of the template rows), {B} sequences x {frames} frames, fixed "
                                    f"template, fresh search crop per frame (ring of {RING} distinct batches = {RING} consecutive frames per hipGraph launch, back to back)",
                        "batch_per_gpu": B, "global_batch": B, "geometry": geom, "frames_per_sequence": frames, "parallelism": "1 GPU",
+                       "streams": nshard, "sequences_per_gpu": B * nshard,
                        "switches": B0.active_switches()},
             "checked": True, "check": checked,
             "frac_f16_peak_whole_step": round(value * 2 * sum(macs.values()) / 1e12 / PEAK_F16_TFLOPS, 5)}
+    if single is not None:
+        line["single_stream_frames_per_s"] = round(single, 1)
     if not a.no_extra:
         also = {}
         for name, prec, cached in (("f16_uncached", "f16", False), ("f32_cached", "f32", True), ("f32_uncached", "f32", False)):
@@ -145,9 +168,9 @@ def measure(a, variants=("f16_uncached", "f32_cached", "f32_uncached")):
             also[name + "_frames_per_s"] = round(B * (frames // 2) / e, 1)
             q.close()
         if "f16_uncached_frames_per_s" in also:
-            also["cache_saving"] = round(1.0 - also["f16_uncached_frames_per_s"] / value, 4)
+            also["cache_saving"] = round(1.0 - also["f16_uncached_frames_per_s"] / (single or value), 4)      # one stream against one stream
         if "f32_cached_frames_per_s" in also:
-            also["f16_over_f32_cached"] = round(value / also["f32_cached_frames_per_s"], 3)
+            also["f16_over_f32_cached"] = round((single or value) / also["f32_cached_frames_per_s"], 3)
         lz, L = (GEOMS[geom][0] // 16) ** 2, (GEOMS[geom][0] // 16) ** 2 + (GEOMS[geom][1] // 16) ** 2
         also["cached_macs_note"] = f"cached per frame: stem(z) + block-0 qkv of {lz} template rows of {L} tokens (SURVEY section 5: ~3.7 % of MACs at G256)"
         line["also"] = also
