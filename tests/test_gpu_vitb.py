@@ -210,3 +210,30 @@ def test_vitb_replays_are_bit_identical(B):
             torch.cuda.synchronize()
             for k, v in ref.items():
                 assert torch.equal(getattr(out, k), v), (it, k)
+
+
+def test_vitb_two_shards_on_two_streams_equal_their_sequential_runs():
+    """bench.py --config vitb --streams 2: two models (own workspaces, own graphs) launched alternately on two streams -- their
+    persistent GEMMs, attention and LayerNorm launches overlap on the chip.  Every output must be what the model gives alone."""
+    import torch
+    from vittracker_amd import synth
+    sd = synth.synth_vitb_state_dict(26)
+    B = 96
+    shards = []
+    for k in range(2):
+        z, x = synth.synth_inputs(21 + k, B, 128, 256)
+        m = _model(sd, B)
+        zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+        graph, out = m.capture(zd, xd)
+        graph.launch()
+        torch.cuda.synchronize()
+        ref = {n: getattr(out, n).clone() for n in ("score_map", "size_map", "offset_map", "hann_boxes", "pred_boxes")}
+        shards.append((m, graph, out, ref, torch.cuda.Stream(), zd, xd))
+    for it in range(6):
+        for m, graph, out, ref, st, zd, xd in shards:
+            graph.launch(st)
+    torch.cuda.synchronize()
+    for m, graph, out, ref, st, zd, xd in shards:
+        for n, v in ref.items():
+            assert torch.equal(getattr(out, n), v), n
+    assert not torch.equal(shards[0][3]["score_map"], shards[1][3]["score_map"])
