@@ -13,8 +13,11 @@
  *   - No entry point that takes a `stream` synchronises with the host or allocates memory, so all
  *     of them may be captured into a hipGraph (the reference syncs once per frame in `.tolist()`,
  *     lib/test/tracker/vit_dist.py:108-109; here the caller decides when to read results back).
- *   - One vt_model per process per GPU; a model is not thread-safe (the reference runs one
- *     tracker instance per worker process, lib/test/evaluation/running.py:105-112).
+ *   - A model is not thread-safe and owns ONE set of workspaces: calls on the same model must not overlap each other (issue
+ *     them on one stream, or order the streams).  Independent models -- each with its own workspaces, weights replica and graphs --
+ *     may run concurrently on different streams of the same GPU: two models stepped alternately on two streams are how many
+ *     independent sequences are served fastest (the reference runs one tracker instance per worker process,
+ *     lib/test/evaluation/running.py:105-112).
  */
 #ifndef VITTRACK_H
 #define VITTRACK_H
