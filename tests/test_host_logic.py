@@ -256,3 +256,18 @@ def test_build_ostrack_config_surface():
     c.MODEL.BACKBONE.TYPE = "vit_base_patch16_224_ce"
     with pytest.raises(NotImplementedError):
         build_ostrack(c, training=False)
+
+
+def test_sharded_tracker_group_sizes():
+    """ShardedBatchedTracker.shard_sizes: contiguous near-equal groups, none empty, order preserved (sequence b stays sequence b)."""
+    from vittracker_amd.batched import ShardedBatchedTracker as S
+    assert S.shard_sizes(256, 2) == [128, 128]
+    assert S.shard_sizes(10, 3) == [4, 3, 3]
+    assert S.shard_sizes(5, 1) == [5]
+    assert S.shard_sizes(2, 4) == [1, 1]              # never more groups than sequences
+    assert S.shard_sizes(1, 2) == [1]
+    for b in range(1, 40):
+        for n in range(1, 6):
+            sz = S.shard_sizes(b, n)
+            assert sum(sz) == b and min(sz) >= 1 and max(sz) - min(sz) <= 1 and sz == sorted(sz, reverse=True)
+

@@ -291,15 +291,20 @@ class ShardedBatchedTracker:
 
     def __init__(self, params, batch: int, shards: int = 2):
         import torch
-        shards = max(1, min(int(shards), int(batch)))
-        base, extra = divmod(int(batch), shards)
-        self.sizes = [base + (1 if k < extra else 0) for k in range(shards)]
-        self.offsets = [sum(self.sizes[:k]) for k in range(shards)]
+        self.sizes = self.shard_sizes(batch, shards)
+        self.offsets = [sum(self.sizes[:k]) for k in range(len(self.sizes))]
         self.B = int(batch)
         self.params = params
         self.trackers = [BatchedVitTracker(params, n) for n in self.sizes]
         self.streams = [torch.cuda.Stream() for _ in self.sizes]
         self.frame_id = 0
+
+    @staticmethod
+    def shard_sizes(batch: int, shards: int):
+        """Contiguous groups of near-equal size, the first `batch % shards` one sequence larger; never an empty group."""
+        shards = max(1, min(int(shards), int(batch)))
+        base, extra = divmod(int(batch), shards)
+        return [base + (1 if k < extra else 0) for k in range(shards)]
 
     def _slices(self):
         return [slice(o, o + n) for o, n in zip(self.offsets, self.sizes)]
