@@ -34,6 +34,8 @@ elif geom == "G128":   # WLDS variant: a barrier splits the MLP
                    f"b{k} barrier3", f"b{k} fc2+gelu2"] for k in range(3)], []) + ["barrier4+tail"]
 else:
     names = sum([[f"b{k} (load)ln1+qkv", f"b{k} barrier1", f"b{k} attn+proj", f"b{k} barrier2", f"b{k} mlp"] for k in range(3)], []) + ["tail"]
+if os.environ.get("STAMP_RAW"):
+    names = [f"s{k}" for k in range(int(os.environ["STAMP_RAW"]))]
 bal = os.environ.get("VT_BLOCKS_BAL", "1") != "0"
 nw = (8 if bal else 5) if geom == "G128" else 4
 buf = buf.reshape(-1)[: B * nw * 64].reshape(B, nw, 64)

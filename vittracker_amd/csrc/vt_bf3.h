@@ -49,6 +49,17 @@ __device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {
 __device__ __forceinline__ f4 mma(u32x4 a, u32x4 b, f4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
+// one 16-deep chunk on its own (an odd last chunk of K): the legacy K = 16 instruction takes the lane's quad as a 64-bit operand and
+// costs the matrix pipe what a K = 32 instruction costs (tools/src/probe_bf3.hip), i.e. what the same chunk paired with zeros would --
+// without the zero registers: no v_mov to widen an operand, two registers less per operand (round 4).
+// RULE: an accumulator chain uses ONE of the two instructions.  A K = 16 MFMA whose SrcC is the result of a K = 32 MFMA issued just
+// before it (or the reverse) read a stale accumulator on gfx950 with hipcc 7.2 -- every replay of the G128 block kernel differed
+// (tools/race_check.py); with the K = 16 terms on an accumulator of their own, added to the other on the VALU, 40 of 40 replays
+// are bit-identical.  The compiler pads same-kind chains and MFMA -> VALU reads correctly; the mixed back-to-back chain it does not.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mma16(u32x2 a, u32x2 b, f4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), acc, 0, 0, 0);
+}
 // the three small terms (l h, h l, m m), then the three large ones (m h, h m, h h), of one K = 32 step: pieces [0] = h, [1] = m, [2] = l
 __device__ __forceinline__ f4 mma_small(const u32x4 (&a)[3], const u32x4 (&b)[3], f4 acc) {
     acc = mma(a[2], b[0], acc);

@@ -162,6 +162,14 @@ __device__ __forceinline__ void barrier_publish() {
     __syncthreads();
 }
 
+// timing experiments only (wrong results): -DVT_BLK_GUESTS=0 compiles the guest waves' work out of the balanced frame form (they keep
+// the barriers), -DVT_BLK_OWNERS=0 the owners' -- what each role costs alone, and what the pairing costs (tools/block_stamps.py)
+#ifndef VT_BLK_GUESTS
+#define VT_BLK_GUESTS 1
+#endif
+#ifndef VT_BLK_OWNERS
+#define VT_BLK_OWNERS 1
+#endif
 #ifndef VT_BLK_NOSTAGE
 #define VT_BLK_NOSTAGE 0       // timing experiments only (wrong results): 1 = no weight staging at all -- the MFMAs then run on whatever the LDS
 #endif                         // held, mostly zeros, cooler and at higher clocks: NOT a measure of what staging costs; 2 (BF3L form) = staging in
@@ -332,16 +340,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         // loop hipcc computed ~38 of them up front and spilled them (reloads wait on vmcnt, i.e. on the weight staging in flight)
         int lane3 = lane;
         if constexpr (BF3) asm volatile("" : "+v"(lane3));
-        const u32x4* const Wa3 = reinterpret_cast<const u32x4*>(Wa);
-        const u32x2* const Wa3h = reinterpret_cast<const u32x2*>(Wa);
-        const u32x4* const Wb3 = reinterpret_cast<const u32x4*>(Wb);
-        const u32x4* const Wk3 = reinterpret_cast<const u32x4*>(Kimg);
-        auto w1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {       // fc1 pieces of output tile t: chunk pair 0, chunk 2
+        // one opaque base register per (region, lane stride): the images' tile / piece offsets then sit in the instructions' offset fields
+        const auto Wa3 = BF3L ? lds_lane_base<u32x4>(Wa, 16u * lane3) : nullptr;                       // pair-0 pieces, 16 B per lane
+        const auto Wa3h = BF3L ? lds_lane_base<u32x2>(Wa, 192u * 16u + 8u * lane3) : nullptr;          // chunk-2 pieces, 8 B per lane
+        const auto Wb3 = BF3L ? lds_lane_base<u32x4>(Wb, 16u * lane3) : nullptr;
+        const auto Wk3 = BF3L ? lds_lane_base<u32x4>(Kimg, 16u * lane3) : nullptr;
+        auto w1_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {       // fc1 pieces of output tile t: chunk pair 0, chunk 2
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                a0[pc] = Wa3[t * W3_FC1_OT16 + pc * 64 + lane3];
-                const u32x2 v = Wa3h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
-                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+                a0[pc] = Wa3[t * W3_FC1_OT16 + pc * 64];
+                a2[pc] = Wa3h[t * W3_FC1_OT16 * 2 + pc * 64];
             }
         };
         auto w2_load3 = [&](int p, u32x4 (&a)[NC][3]) {                     // fc2 pieces of chunk pair p, all three output tiles
@@ -349,28 +357,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             for (int ot = 0; ot < NC; ++ot)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    a[ot][pc] = ot < 2 ? Wb3[((ot * (NH / 2) + p) * 3 + pc) * 64 + lane3] : Wk3[(p * 3 + pc) * 64 + lane3];
+                    a[ot][pc] = ot < 2 ? Wb3[((ot * (NH / 2) + p) * 3 + pc) * 64] : Wk3[(p * 3 + pc) * 64];
         };
-        auto split_h3 = [&](const f4 (&h)[NC], u32x4 (&hb)[3], u32x4 (&hc)[3]) {       // LN2's output as fc1's B operands
-            u32x2 a[3], b2[3], c[3];
+        auto split_h3 = [&](const f4 (&h)[NC], u32x4 (&hb)[3], u32x2 (&hc)[3]) {       // LN2's output as fc1's B operands
+            u32x2 a[3], b2[3];
             vt3::split3(h[0], a[0], a[1], a[2]);
             vt3::split3(h[1], b2[0], b2[1], b2[2]);
-            vt3::split3(h[2], c[0], c[1], c[2]);
+            vt3::split3(h[2], hc[0], hc[1], hc[2]);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                hb[pc] = u32x4{a[pc].x, a[pc].y, b2[pc].x, b2[pc].y};
-                hc[pc] = u32x4{c[pc].x, c[pc].y, 0u, 0u};
-            }
+            for (int pc = 0; pc < 3; ++pc) hb[pc] = u32x4{a[pc].x, a[pc].y, b2[pc].x, b2[pc].y};
         };
-        // one 16 x 16 output tile of a K = 48 layer: 12 MFMAs as two chains (chunk pair 0 onto `init`, chunk 2 onto zero), added.
-        // SWAP: the activation pieces are the A operand (rows = tokens): v, so that V^T comes out.
-        auto tile48 = [&](auto swap, const u32x4 (&a0)[3], const u32x4 (&a2)[3], const u32x4 (&hb)[3], const u32x4 (&hc)[3], f4 init) {
+        // one 16 x 16 output tile of a K = 48 layer: 12 MFMAs as two chains (chunk pair 0 onto `init`; chunk 2, on the K = 16
+        // instruction, onto zero), added.  SWAP: the activation pieces are the A operand (rows = tokens): v, so that V^T comes out.
+        auto tile48 = [&](auto swap, const u32x4 (&a0)[3], const u32x2 (&a2)[3], const u32x4 (&hb)[3], const u32x2 (&hc)[3], f4 init) {
             constexpr bool SWAP = decltype(swap)::value;
             constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
             f4 accA = init, accB = splat4(0.f);
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                accB = SWAP ? vt3::mma(hc[TX[e]], a2[TW[e]], accB) : vt3::mma(a2[TW[e]], hc[TX[e]], accB);
+                accB = SWAP ? vt3::mma16(hc[TX[e]], a2[TW[e]], accB) : vt3::mma16(a2[TW[e]], hc[TX[e]], accB);
                 accA = SWAP ? vt3::mma(hb[TX[e]], a0[TW[e]], accA) : vt3::mma(a0[TW[e]], hb[TX[e]], accA);
             }
             return accA + accB;
@@ -390,50 +395,54 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             int lane_z = lane;
             if constexpr (ZC) asm volatile("" : "+v"(lane_z));
             f4* const zc = reinterpret_cast<f4*>(zcache) + (((size_t)b * (len_z >> 4) + T) * 3 * NC) * 64 + lane_z;
-            if (T < NOWN && T != dbg_skip_tile && z_tile && zcache_mode == 2) {
+            if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && z_tile && zcache_mode == 2) {
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
                     qr[i][ot] = zc[ot * 64];
                     Kimg[(T * NC + ot) * 64 + lane] = zc[(NC + ot) * 64];
                     Vimg[(ot * NT + T) * 64 + lane] = zc[(2 * NC + ot) * 64];
                 }
-            } else if (T < NOWN && T != dbg_skip_tile) {
+            } else if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
                 layer_norm_plain(x[i], h);
                 fstamp();
                 if constexpr (BF3) {
-                    u32x4 hb[3], hc[3];
+                    u32x4 hb[3];
+                    u32x2 hc[3];
                     split_h3(h, hb, hc);
                     // qkv pieces of output tile t: from the staging buffer (BF3L) or straight from L2 (BF3G), the next tile's in flight
                     const u32x4* const Gq = reinterpret_cast<const u32x4*>(P3) + (W3_FC1_TILES + W3_FC2_TILES) * 64;
                     const u32x2* const Gqh = reinterpret_cast<const u32x2*>(Gq);
-                    auto wq_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {
+                    auto wq_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {
                         if constexpr (BF3L) w1_load3(t, a0, a2);
                         else {
 #pragma unroll
                             for (int pc = 0; pc < 3; ++pc) {
                                 a0[pc] = Gq[t * W3_FC1_OT16 + pc * 64 + lane3];
-                                const u32x2 v = Gqh[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
-                                a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+                                a2[pc] = Gqh[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
                             }
                         }
                     };
-                    u32x4 a0[2][3], a2[2][3];
+                    u32x4 a0[2][3];
+                    u32x2 a2[2][3];
+                    // a tile's accumulator initialiser (its bias) is requested WITH its weight pieces, one tile ahead: requested beside
+                    // the next tile's pieces it was the youngest LDS read in flight, so the wait in front of the tile's first MFMA was
+                    // lgkmcnt(0) -- for the prefetch just issued: one exposed LDS round trip per tile (round 4)
+                    auto bias_q = [&](int t) { return t < 2 * NC ? ld4(S + S_BQKV + 16 * t + 4 * q) : splat4(S[S_BQKV + 2 * C + 16 * (t % NC) + tok]); };
+                    f4 bias[2];
                     wq_load3(0, a0[0], a2[0]);
+                    bias[0] = bias_q(0);
 #pragma unroll
                     for (int t = 0; t < 3 * NC; ++t) {
-                        if (t + 1 < 3 * NC) wq_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                        if (t + 1 < 3 * NC) {
+                            wq_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                            bias[(t + 1) & 1] = bias_q(t + 1);
+                        }
                         const int ot = t % NC;
                         f4 r;
-                        if (t < 2 * NC) {
-                            const f4 bias = ld4(S + S_BQKV + 16 * t + 4 * q);
-                            __builtin_amdgcn_sched_barrier(0);
-                            r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias);
-                        } else {
-                            const f4 bias = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
-                            __builtin_amdgcn_sched_barrier(0);
-                            r = tile48(std::true_type{}, a0[t & 1], a2[t & 1], hb, hc, bias);
-                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t < 2 * NC) r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
+                        else r = tile48(std::true_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
                         if (t < NC) qr[i][ot] = r;
                         else if (t < 2 * NC) Kimg[(T * NC + ot) * 64 + lane] = r;
                         else Vimg[(ot * NT + T) * 64 + lane] = r;
@@ -479,12 +488,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         if constexpr (BAL) {
-            if (BF3L && w >= NOWN && g < 3) {
+            if (BF3L && VT_BLK_GUESTS && w >= NOWN && g < 3) {
                 f4 h[NC];
                 layer_norm_plain(x4, h);
-                u32x4 hb[3], hc[3];
+                u32x4 hb[3];
+                u32x2 hc[3];
                 split_h3(h, hb, hc);
-                u32x4 a0[NC][3], a2[NC][3];
+                u32x4 a0[NC][3];
+                u32x2 a2[NC][3];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) w1_load3(NC * g + j, a0[j], a2[j]);
                 f4 r[NC];
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < NC; ++j) Vimg[(j * NT + GT) * 64 + lane] = r[j];
                 }
-            } else if (w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
+            } else if (VT_BLK_GUESTS && w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
                 f4 h[NC];
                 layer_norm_plain(x4, h);
                 f4 acc[NC];
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+            if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                 // softmax((q k^T) * scale) (attn.py:40-41) as exp2(raw * (scale log2 e) - max_raw * (scale log2 e)): the scale, the
                 // subtraction and exp's own log2 e factor become ONE packed fma per two scores, the row maximum runs on v_max3 and the
                 // row sum on packed adds -- 10 instead of 22 VALU instructions per score tile (scale > 0: the raw maximum is the maximum)
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         if constexpr (BAL) {
-            if (w >= NOWN) {
+            if (VT_BLK_GUESTS && w >= NOWN) {
                 // partial attention of the guest queries over this guest's key tiles
                 auto attn_part = [&](auto njc, int J0) {
                     constexpr int NJ = decltype(njc)::value;
@@ -784,9 +795,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         // upper half), the next unit's weight pieces requested ahead, GELU + the split of the previous unit under the current
         // unit's MFMAs.  Unit u's two hidden tiles ARE fc2's chunk pair u, so the split results are fc2's B operands as they stand.
         // N chains x 12 MFMAs: the small terms of both K steps first, then the large ones
-        auto fc1_terms3 = [&](auto nc, const u32x4 (*a0)[3], const u32x4 (*a2)[3], const u32x4 (&hb)[3], const u32x4 (&hc)[3], f4* acc) {
+        auto fc1_terms3 = [&](auto nc, const u32x4 (*a0)[3], const u32x2 (*a2)[3], const u32x4 (&hb)[3], const u32x2 (&hc)[3], f4* acc) {
             constexpr int N = decltype(nc)::value;
             constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            f4 accB[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) accB[j] = splat4(0.f);
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -796,8 +810,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                         for (int j = 0; j < N; ++j) {
                             const int e = 3 * half + t3;
-                            acc[j] = k == 0 ? vt3::mma(a2[j][TW[e]], hc[TX[e]], acc[j]) : vt3::mma(a0[j][TW[e]], hb[TX[e]], acc[j]);
+                            if (k == 0) accB[j] = vt3::mma16(a2[j][TW[e]], hc[TX[e]], accB[j]);
+                            else acc[j] = vt3::mma(a0[j][TW[e]], hb[TX[e]], acc[j]);
                         }
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = acc[j] + accB[j];
         };
         u32x4 hq[NHID][NH / 2][3];       // GELU(fc1) as pieces: [chunk pair][piece] = {quad of chunk 2 p | quad of chunk 2 p + 1}
         auto mlp_first3 = [&](int i, int hi) {
@@ -805,7 +822,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             layer_norm_plain(x[i], h);
 #pragma unroll
             for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
-            u32x4 hb[3], hc[3];
+            u32x4 hb[3];
+            u32x2 hc[3];
             split_h3(h, hb, hc);
             fstamp();
             // one hidden tile per step, its 12 MFMAs as two independent chains (chunk pair 0 onto the bias, chunk 2 onto zero) that
@@ -815,8 +833,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             // accumulator chains for ~190 cycles with nothing else to issue) and the VALU work behind it; sched_group_barrier
             // requests did not change that here, and without the asm pin LLVM sinks the whole chain below the following tiles.
             constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
-            u32x4 a0[2][3], a2[2][3];
+            u32x4 a0[2][3];
+            u32x2 a2[2][3];
             w1_load3(0, a0[0], a2[0]);
+            f4 bias1[2];
+            bias1[0] = ld4(S + S_B1 + 4 * q);
             f4 prev = splat4(0.f);
             u32x2 pl[3];            // pieces of the pair's first tile
             f2 ua, ub, na, nb, pa, pb, ea, eb;      // GELU state between stages (pairs (x, y) and (z, w) of `prev`)
@@ -873,14 +894,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 if (t == 4 || t == 8) fstamp();
                 f4 accA = splat4(0.f), accB = splat4(0.f);
                 if (t < NH) {
-                    if (t + 1 < NH) w1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
-                    accA = ld4(S + S_B1 + 16 * t + 4 * q);
+                    accA = bias1[t & 1];
+                    if (t + 1 < NH) {       // the next tile's pieces AND its bias, a tile ahead (see the qkv loop)
+                        w1_load3(t + 1, a0[(t + 1) & 1], a2[(t + 1) & 1]);
+                        bias1[(t + 1) & 1] = ld4(S + S_B1 + 16 * (t + 1) + 4 * q);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 6; ++e) {
                     if (t < NH) {
-                        accB = vt3::mma(a2[t & 1][TW[e]], hc[TX[e]], accB);
+                        accB = vt3::mma16(a2[t & 1][TW[e]], hc[TX[e]], accB);
                         accA = vt3::mma(a0[t & 1][TW[e]], hb[TX[e]], accA);
                     }
                     if (t > 0) {
@@ -912,19 +936,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first3(i, i);
+                if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first3(i, i);
             }
             u32x2 gq[NC][3];     // the guest's GELU(fc1) tiles 3 g .. 3 g + 2 as pieces
-            if (w >= NOWN) {
+            if (VT_BLK_GUESTS && w >= NOWN) {
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q) + Dg[ot * 64 + lane];
                 f4 h[NC];
                 layer_norm_plain(x4, h);
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
-                u32x4 hb[3], hc[3];
+                u32x4 hb[3];
+                u32x2 hc[3];
                 split_h3(h, hb, hc);
-                u32x4 a0[NC][3], a2[NC][3];
+                u32x4 a0[NC][3];
+                u32x2 a2[NC][3];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) w1_load3(NC * g + j, a0[j], a2[j]);
                 f4 acc[NC];
@@ -942,25 +968,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second3(i, i);
+                if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second3(i, i);
             }
-            if (w >= NOWN) {
+            if (VT_BLK_GUESTS && w >= NOWN) {
                 // fc2 restricted to this guest's hidden tiles 3 g .. 3 g + 2 = one whole chunk pair and half of another (the other
                 // half of that pair belongs to the neighbouring guest: zeros in this guest's B operand)
                 const bool odd = g & 1;
                 const int p_full = (3 * g + (odd ? 1 : 0)) >> 1, p_half = (3 * g + (odd ? 0 : 2)) >> 1;
-                u32x4 bf[3], bh[3];
+                u32x4 bf[3];
+                u32x2 bh[3];
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
                     bf[pc] = odd ? u32x4{gq[1][pc].x, gq[1][pc].y, gq[2][pc].x, gq[2][pc].y} : u32x4{gq[0][pc].x, gq[0][pc].y, gq[1][pc].x, gq[1][pc].y};
-                    bh[pc] = odd ? u32x4{0u, 0u, gq[0][pc].x, gq[0][pc].y} : u32x4{gq[2][pc].x, gq[2][pc].y, 0u, 0u};
+                    bh[pc] = odd ? gq[0][pc] : gq[2][pc];
                 }
-                u32x4 af[NC][3], ah[NC][3];
+                u32x4 af[NC][3];
+                u32x2 ah[NC][3];       // the half pair: the weights' quad of this guest's chunk only (K = 16 instruction)
                 w2_load3(p_full, af);
-                w2_load3(p_half, ah);
-                f4 part[NC];
+                {
+                    // chunk 2 p + 1 = the upper quad of the lane's 16 bytes, chunk 2 p the lower; p_half is wave-uniform, not constant
+                    const unsigned hoff = 16u * lane3 + (odd ? 8u : 0u) + (unsigned)p_half * (3u * 64u * 16u);
+                    const auto Wb3h = lds_lane_base<u32x2>(Wb, hoff);
+                    const auto Wk3h = lds_lane_base<u32x2>(Kimg, hoff);
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
+                    for (int ot = 0; ot < NC; ++ot)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            ah[ot][pc] = ot < 2 ? Wb3h[((ot * (NH / 2)) * 3 + pc) * 64 * 2] : Wk3h[pc * 64 * 2];
+                }
+                f4 part[NC], partB[NC];
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) part[ot] = partB[ot] = splat4(0.f);
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -972,8 +1010,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) {
                                 const int e = 3 * half + t3;
-                                part[ot] = k == 0 ? vt3::mma(ah[ot][TW[e]], bh[TX[e]], part[ot]) : vt3::mma(af[ot][TW[e]], bf[TX[e]], part[ot]);
+                                if (k == 0) partB[ot] = vt3::mma16(ah[ot][TW[e]], bh[TX[e]], partB[ot]);
+                                else part[ot] = vt3::mma(af[ot][TW[e]], bf[TX[e]], part[ot]);
                             }
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) part[ot] = part[ot] + partB[ot];
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) Pg[(g * NC + ot) * 64 + lane] = part[ot];
             }
@@ -981,11 +1022,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first(i, i);
+                if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_first(i, i);
             }
             f4 ghid[NC];        // BAL: GELU(fc1) of this guest's three hidden tiles
             if constexpr (BAL) {
-                if (w >= NOWN) {
+                if (VT_BLK_GUESTS && w >= NOWN) {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q) + Dg[ot * 64 + lane];
                     f4 h[NC];
@@ -1012,10 +1053,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int T = w + NW * i;
-                if (T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second(i, i);
+                if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) mlp_second(i, i);
             }
             if constexpr (BAL) {
-                if (w >= NOWN) {   // fc2 restricted to this guest's hidden tiles: a partial sum of the update
+                if (VT_BLK_GUESTS && w >= NOWN) {   // fc2 restricted to this guest's hidden tiles: a partial sum of the update
                     f4 part[NC];
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
@@ -1042,21 +1083,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     const u32x4* const G1 = reinterpret_cast<const u32x4*>(P3);
                     const u32x2* const G1h = reinterpret_cast<const u32x2*>(P3);
                     const u32x4* const G2 = G1 + W3_FC1_TILES * 64;
-                    auto g1_load3 = [&](int t, u32x4 (&a0)[3], u32x4 (&a2)[3]) {
+                    auto g1_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc) {
                             a0[pc] = G1[t * W3_FC1_OT16 + pc * 64 + lane3];
-                            const u32x2 v = G1h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
-                            a2[pc] = u32x4{v.x, v.y, 0u, 0u};
+                            a2[pc] = G1h[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
                         }
                     };
                     f4 h[NC];
                     layer_norm_plain(x[i], h);
-                    u32x4 hb[3], hc[3];
+                    u32x4 hb[3];
+                    u32x2 hc[3];
                     split_h3(h, hb, hc);
                     u32x4 hq3[NH / 2][3];
                     {
-                        u32x4 a0[2][3], a2[2][3];
+                        u32x4 a0[2][3];
+                        u32x2 a2[2][3];
                         g1_load3(0, a0[0], a2[0]);
                         u32x2 pl[3];
 #pragma unroll

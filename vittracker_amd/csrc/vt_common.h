@@ -74,6 +74,20 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
 
 __device__ __forceinline__ f4 splat4(float v) { return f4{v, v, v, v}; }
 
+// A lane's base address inside an LDS region as ONE opaque VGPR: every access `p[constant index]` through the returned pointer is
+// then a ds_read / ds_write with the index in the instruction's 16-bit offset field.  Left to itself hipcc folds the region's own
+// offset into the immediate, runs out of the 64 KiB the field covers (the weight staging buffers lie above 30 KiB and are 54 KiB
+// long) and builds the addresses one v_add_u32 per access instead (round 4: 177 of the G128 block kernel's ~2000 static VALU
+// instructions).  `generic` must point into LDS.
+template <typename T>
+using lds_cptr = const __attribute__((address_space(3))) T*;
+template <typename T>
+__device__ __forceinline__ lds_cptr<T> lds_lane_base(const void* generic, unsigned lane_byte_off) {
+    unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)generic + lane_byte_off;
+    asm volatile("" : "+v"(a));
+    return (lds_cptr<T>)(uintptr_t)a;
+}
+
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 // streaming store: the line is not kept dirty in this XCD's L2 until the end-of-kernel write-back

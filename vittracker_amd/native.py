@@ -13,7 +13,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvittrack_hip.so")
+#: VITTRACK_LIB=<path> selects another build of the fp32 library (A/B tools: tools/ab_stages.py, tools/block_stamps.py)
+LIB_PATH = os.environ.get("VITTRACK_LIB") or os.path.join(_HERE, "csrc", "libvittrack_hip.so")
 #: the same sources built with every vit_48 contraction on f16 MFMA (BASELINE config 5; make -C csrc all)
 LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvittrack_hip_f16.so")
 PRECISIONS = ("f32", "f16")
