@@ -177,6 +177,14 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
 int vt_graph_launch(vt_graph* g, void* stream);
 void vt_graph_destroy(vt_graph* g);
 
+/* Kernel forms by group size.  Every stage has several kernel forms and picks one by the batch of the call (the
+ * one-workgroup-per-frame forms once the batch fills the chip, multi-workgroup forms below); two forms of a stage agree to fp32
+ * rounding (~4e-6), not bit for bit.  A caller that steps a group of N sequences as several models of N / k sequences each (one per
+ * stream or per GPU: the reference shards sequences over worker processes, lib/test/evaluation/running.py:105-112) sets n = N on every
+ * one of them: each shard then runs the forms the whole group would run, and a sequence's results do not depend on how the group is
+ * sharded.  n = 0 (default): forms by each call's own batch.  A call with a batch larger than n uses its own batch. */
+int vt_set_form_batch(vt_model* m, int32_t n);
+
 /* Geometry / workspace queries (host side of build_box_head: feat_sz etc.). */
 int vt_query(const vt_model* m, int32_t* len_z, int32_t* len_x, int32_t* feat_sz, int32_t* channels);
 

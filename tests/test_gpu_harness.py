@@ -100,6 +100,42 @@ def test_bench_record_graph_form_on_one_gpu():
     assert j["checked"] and j["value"] > 0 and j["config"]["steps_per_graph"] == 4 and j["steps"] == 11
 
 
+@pytest.mark.parametrize("streams", ["1", "2"])
+def test_bench_force_gather_runs_the_rccl_leg_on_one_gpu(streams):
+    """Round 3 review: the RCCL leg of bench.py (init_process_group('nccl'), all_gather_into_tensor(async_op=True) per launch unit under
+    the shard's stream, record graphs writing straight into the gather buffers) had only ever run on gloo.  --force-gather starts the
+    single rank under torch.distributed.run (before any GPU call), builds a 1-rank RCCL communicator and runs exactly that form;
+    bench.py itself checks gathered == the records the graphs wrote == a plain forward."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-gather", "--streams", streams, "--steps", "43",
+                        "--warmup", "9", "--no-cpu", "--no-extra"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["checked"] and j["value"] > 0 and j["n_gpus"] == 1 and j["steps"] == 43
+    assert j["gather"]["backend"] == "nccl" and j["gather"]["ranks"] == 1 and j["gather"]["records_checked"]
+    assert "gather_exposed_us_per_step" in j and j["config"]["streams"] == int(streams)
+
+
+def test_force_gather_form_is_as_fast_as_the_plain_form():
+    """N = 1 with the real collective agrees with the plain form within 3 % (best of three alternating runs each)."""
+    import json
+    import subprocess
+    import sys
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "400", "--warmup", "50", "--no-cpu", "--no-extra"] + extra,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["value"]
+    plain, gat = [], []
+    for _ in range(3):
+        plain.append(run([]))
+        gat.append(run(["--gpus", "1", "--force-gather"]))
+    assert abs(max(gat) / max(plain) - 1.0) < 0.03, (plain, gat)
+
+
 def test_record_graph_form_is_as_fast_as_the_plain_form():
     """SCALE N = 1 must agree with BENCH: at the metric's batch the record-graph launch form (what every rank runs when N > 1)
     and the plain form report the same frames/s (best of three alternating runs each, within 3 %)."""
@@ -174,3 +210,42 @@ def test_sharded_batched_tracker_equals_one_batched_tracker():
         for a, b in zip(want, got):
             np.testing.assert_array_equal(a, b)
 
+
+
+@pytest.mark.parametrize("yaml_name,B,shards", [("vit_48_h32_g128", 256, 4), ("vit_48_h32_noKD", 256, 2)])
+def test_sharding_a_full_group_does_not_change_its_results(yaml_name, B, shards):
+    """Round 3 advisor: the library picks a stage's kernel form by batch size (frame forms above 80 / 128 / 176 sequences, tile and
+    multi-workgroup forms below), and two forms agree to fp32 rounding only -- so 256 sequences as two models of 128 ran other
+    kernels than one model of 256.  Every shard now selects its forms by the WHOLE group's size (vt_set_form_batch): boxes and
+    confidences of the sharded run equal the unsharded run bit for bit, at the full batch, at both geometries; and a shard that
+    does NOT know the group's size (form_batch = 0) is shown to run different forms (else this test would prove nothing)."""
+    import torch
+    from vittracker_amd.batched import BatchedVitTracker, ShardedBatchedTracker
+    from vittracker_amd.parameter import vit_dist as P
+    os.environ.setdefault("VITTRACK_PRJ_DIR", REPO)
+    p = P.parameters(yaml_name)
+    p.allow_synthetic_weights = True
+    H, W = 96, 128
+    rs = np.random.RandomState(11)
+    frames = rs.randint(0, 256, (4, B, H, W, 3)).astype(np.uint8)
+    boxes = np.stack([rs.uniform(20, 70, B), rs.uniform(20, 50, B), rs.uniform(15, 40, B), rs.uniform(15, 40, B)], 1)
+
+    def run(bt):
+        bt.initialize(frames[0], boxes)
+        out = []
+        for t in (1, 2, 3):
+            r = bt.track(frames[t])
+            out.append((r["target_bbox"].numpy().copy(), r["confidence"].numpy().copy()))
+        return out
+    want = run(BatchedVitTracker(p, B))
+    got = run(ShardedBatchedTracker(p, B, shards))      # shards of 64 (G128) / 128 (G256): batches that would pick the tile-form blocks
+    for (wb, wc), (gb, gc) in zip(want, got):
+        np.testing.assert_array_equal(wb, gb)
+        np.testing.assert_array_equal(wc, gc)
+    # the control: a shard-size tracker left to choose its forms by its own batch is NOT bit-identical to its part of the group
+    n = B // shards
+    part = BatchedVitTracker(p, n)
+    part.initialize(frames[0][:n], boxes[:n])
+    r = part.track(frames[1][:n])
+    assert not np.array_equal(r["confidence"].numpy(), want[0][1][:n])
+    np.testing.assert_allclose(r["confidence"].numpy(), want[0][1][:n], atol=1e-4)

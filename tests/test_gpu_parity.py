@@ -83,6 +83,40 @@ def test_each_stage_against_reference_activations(path):
         np.testing.assert_allclose(getattr(out, k).cpu().numpy(), g[k], atol=TOL_MAP, rtol=0, err_msg="head " + k)
 
 
+@pytest.mark.parametrize("stem_bf3", ["1", "0"])
+@pytest.mark.parametrize("path", [p for p in golden_files() if "_b1" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_each_large_batch_stage_form_against_reference_activations(path, stem_bf3, monkeypatch):
+    """The same stage-by-stage check for the kernels the headline bench times: a batch of one with the model's form batch set to
+    256 (vt_set_form_batch) runs stem_fused / stem_stream, the frame-form block kernel and head_fused3 / head_seq -- each fed the
+    REFERENCE's upstream activation (round 3 review: stem_fused was only covered end to end).  Both settings of VT_STEM_BF3."""
+    monkeypatch.setenv("VT_STEM_BF3", stem_bf3)
+    g, sd, z, x = load_case(path)
+    geom = str(g["geom"])
+    m = _model(sd, geom, 1)
+    m.set_form_batch(256)
+    torch = _torch()
+
+    def tok(a, pos):
+        B, C, H, W = a.shape
+        return a.reshape(B, C, H * W).transpose(0, 2, 1) + pos
+    ref_tokens = np.concatenate([tok(g["act_stem3_z"], sd["pos_embed_z"]), tok(g["act_stem3_x"], sd["pos_embed_x"])], 1)
+    got = m.stem(_dev(z), _dev(x)).cpu().numpy()
+    np.testing.assert_allclose(got, ref_tokens, atol=TOL_ACT, rtol=0, err_msg="stem tokens (large-batch form)")
+    tokens = _dev(ref_tokens.astype(np.float32))
+    for nb in (1, 2, 3):
+        feat, resid = m.blocks(tokens, nblocks=nb, want_resid=True)
+        np.testing.assert_allclose(resid.cpu().numpy(), g[f"act_block{nb - 1}"], atol=TOL_ACT, rtol=0,
+                                   err_msg=f"residual after block {nb - 1} (frame form)")
+    np.testing.assert_allclose(feat.cpu().numpy(), g["act_norm"][:, -m.len_x:], atol=TOL_ACT, rtol=0, err_msg="norm")
+    out = m.head(_dev(g["act_norm"][:, -m.len_x:].astype(np.float32)))
+    torch.cuda.synchronize()
+    for k in ("score_map", "size_map", "offset_map"):
+        np.testing.assert_allclose(getattr(out, k).cpu().numpy(), g[k], atol=TOL_MAP, rtol=0, err_msg="head " + k)
+    # and the forms really differ from the small-batch ones (else this test repeats the one above)
+    small = _model(sd, geom, 1)
+    assert not np.array_equal(small.stem(_dev(z), _dev(x)).cpu().numpy(), got)
+
+
 def test_oracle_agrees_on_fresh_seeds_g128():
     """Seeds with no committed fixture: HIP vs the pinned numpy oracle (maps) and, where the
     oracle's argmax margin allows, boxes."""

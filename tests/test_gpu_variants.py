@@ -57,6 +57,9 @@ VARIANTS = {
     "head_fp32_mfma_fused_form": {"VT_HEAD_BF3": "0", "VT_HEAD_FUSED": "1"},
     # the G128 frame form's MLP on fp32 MFMAs (the default multiplies exact three-piece bf16 splits: vt_blocks.h BF3, vt_bf3.h)
     "blocks_mlp_fp32_mfma": {"VT_BLOCKS_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
+    # layer 3 of the fused G128 stem on fp32 MFMAs (the default multiplies exact three-piece bf16 splits there too)
+    "stem_fused_layer3_fp32_mfma": {"VT_STEM_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
+    "everything_on_fp32_mfma": {"VT_STEM_BF3": "0", "VT_BLOCKS_BF3": "0", "VT_HEAD_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
     "g256_head_conv1_split_forced": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "1"},
     "blocks_wave_per_tile_lds_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "1", "VT_BLOCKS_TILE": "0"},
     "blocks_wave_per_tile_l2_weights": {"VT_BLOCKS_BAL": "0", "VT_BLOCKS_WLDS": "0", "VT_BLOCKS_TILE": "0"},
@@ -187,3 +190,31 @@ def test_bf16_split_forms_agree_with_fp32_mfma_forms_on_a_full_batch(geom, tmp_p
     same = np.abs(a["pred"] - b["pred"]).max(axis=1) <= 1e-5
     assert same.mean() >= 0.99, float(same.mean())
 
+
+
+@pytest.mark.parametrize("geom", ["G128", "G256"])
+def test_form_batch_makes_a_small_batch_run_the_large_batch_forms(geom):
+    """vt_set_form_batch(256): a batch of 8 then runs the one-workgroup-per-frame forms a batch of 256 runs, so its outputs equal the
+    first 8 frames of the 256-batch bit for bit (without it: the multi-workgroup forms, equal to fp32 rounding only)."""
+    import torch
+    from vittracker_amd import native, synth
+    tz, tx = {"G128": (64, 128), "G256": (128, 256)}[geom]
+    sd = synth.synth_state_dict(0, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    z, x = synth.synth_inputs(4, 256, tz, tx)
+    zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+    big = native.Model(tz, tx, max_batch=256)
+    big.load_state_dict(sd)
+    ob = big.forward(zd, xd)
+    small = native.Model(tz, tx, max_batch=8)
+    small.load_state_dict(sd)
+    plain = small.forward(zd[:8].contiguous(), xd[:8].contiguous())
+    keys = ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf")
+    plain = {k: getattr(plain, k).clone() for k in keys}
+    small.set_form_batch(256)
+    formed = small.forward(zd[:8].contiguous(), xd[:8].contiguous())
+    for k in keys:
+        assert torch.equal(getattr(formed, k), getattr(ob, k)[:8]), (geom, k)
+    assert any(not torch.equal(plain[k], getattr(ob, k)[:8]) for k in keys)
+    assert float((plain["score_map"] - ob.score_map[:8]).abs().max()) < 1e-4
+    with pytest.raises(native.VtError):
+        small.set_form_batch(-1)

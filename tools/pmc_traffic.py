@@ -7,14 +7,15 @@ d, key = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # every counter of every pass, averaged per dispatch: bench.py quotes SQ_VALU_MFMA_BUSY_CYCLES etc. of the dominant kernel
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in acc.items():
     if "rocclr" in k or "at::" in k:
         continue
     f = sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"])); w = sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"]))
-    out[k] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    out[k] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+              "counters": {n: round(sum(v) / len(v), 1) for n, v in sorted(c.items()) if n not in ("FETCH_SIZE", "WRITE_SIZE") and v}}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")
 allj = json.load(open(path)) if os.path.exists(path) else {}
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -34,7 +34,10 @@ def check_params_geometry(params, nat):
 class BatchedVitTracker:
     ZERO_COPY_MAX_BYTES = 2 << 20      # host frames up to this size (all sequences together) are read in place from pinned memory
 
-    def __init__(self, params, batch: int):
+    def __init__(self, params, batch: int, form_batch: int = 0):
+        """form_batch: this tracker steps `batch` sequences of a larger group of `form_batch` (a shard of ShardedBatchedTracker, a rank
+        of run_dataset_batched): its kernels take the forms the whole group would run (native.Model.set_form_batch), so that the
+        group's results do not depend on how it is sharded."""
         import torch
         self.params = params
         self.cfg = params.cfg
@@ -49,6 +52,8 @@ class BatchedVitTracker:
             raise FileNotFoundError(f"checkpoint {ckpt!r} not found")
         self.net.cuda().eval()
         self.nat = self.net._native()
+        if form_batch:
+            self.nat.set_form_batch(form_batch)
         check_params_geometry(params, self.nat)
         F = params.search_size // self.cfg.MODEL.BACKBONE.STRIDE
         self.nat.set_window(hann2d(torch.tensor([F, F]).long()).numpy())
@@ -151,7 +156,7 @@ class BatchedVitTracker:
 
     def track_record(self, frames):
         """track(frames, sync=True) for callers that want the raw per-sequence records: a (B,5) float64 numpy array
-        [x, y, w, h, confidence] (a view of the step's pinned record when the fast path applies: valid until the call after next).
+        [x, y, w, h, confidence] that the caller owns.
         The plugin tracker's per-frame call: for host frames that are read in place (see _upload) a repeat call is one CPU copy,
         one graph launch, one stream synchronisation and nothing else."""
         import torch
@@ -163,13 +168,15 @@ class BatchedVitTracker:
                 if self.graph is None:
                     raise VtError("track before initialize")
                 self._slot = k ^ 1
+                if self._slot_done[k] is not None:            # a step queued by track(sync=False) / initialize() may still read this slot
+                    self._slot_done[k].synchronize()
+                    self._slot_done[k] = None
                 np.copyto(ent[0], a)
                 self._cur_slot = k
-                self._slot_done[k] = None
                 ent[1].replay()
                 torch.cuda.current_stream().synchronize()
                 self.frame_id += 1
-                return ent[2][0]
+                return ent[2][0].copy()                       # the caller owns it (40 bytes per sequence), as on the slow path
         out = self.track(frames, sync=True)
         return torch.cat([out["target_bbox"], out["confidence"].double().view(-1, 1)], dim=1).numpy()
 
@@ -286,8 +293,10 @@ class ShardedBatchedTracker:
     CU's LDS, so a single stream leaves the chip idle at each kernel's ramp and tail and between two graph launches; with two
     groups in flight the next graph's first kernel takes over the CUs the previous graph's last kernel is leaving (DESIGN.md 4.5:
     +5 % end to end at B = 2 x 256, +10-18 % on the network alone).  Same interface and the same results per sequence as one
-    BatchedVitTracker of B sequences (initialize / track / track_chunk; host or device frames), bit for bit: a sequence's
-    kernels do not depend on which other sequences share its batch."""
+    BatchedVitTracker of B sequences (initialize / track / track_chunk; host or device frames), bit for bit: every shard's model
+    selects its kernel forms by the WHOLE group's size (vt_set_form_batch; the forms of a stage differ by fp32 rounding, and the
+    library picks them by batch size), and within one form a sequence's kernels do not depend on which other sequences share
+    its batch (tests/test_gpu_harness.py: B = 256 in two shards at both geometries)."""
 
     def __init__(self, params, batch: int, shards: int = 2):
         import torch
@@ -295,7 +304,7 @@ class ShardedBatchedTracker:
         self.offsets = [sum(self.sizes[:k]) for k in range(len(self.sizes))]
         self.B = int(batch)
         self.params = params
-        self.trackers = [BatchedVitTracker(params, n) for n in self.sizes]
+        self.trackers = [BatchedVitTracker(params, n, form_batch=self.B) for n in self.sizes]
         self.streams = [torch.cuda.Stream() for _ in self.sizes]
         self.frame_id = 0
 

@@ -106,10 +106,12 @@ struct vt_model {
     int stem_stream = -1;  // stem_stream_kernel (all four layers of a frame streamed band by band through one workgroup) instead of
                            // stem_pipe + stem_b (G256) / stem_fused (G128); auto: G256 B > 176 (fp32 build)
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
+    int stem_bf3 = 1;      // VT_STEM_BF3: layer 3 of stem_fused as exact three-piece bf16 products (fp32 build); 0 = fp32 MFMAs
     int blocks_bf3_g256 = 1;   // the same switch at G256 (MLP only, weights from L2)
     int blocks_bf3 = 1;    // VT_BLOCKS_BF3: the G128 frame form's MLP as exact three-piece bf16 products (0 = fp32 MFMA)
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
+    int form_batch = 0;    // vt_set_form_batch: kernel forms are chosen as for a batch of this size (0: by the batch of each call)
     int plan_r2[2] = {0, 0}, plan_r4[2] = {0, 0};   // band plan for (search, template) crops
     bool r4_128_forced = false;   // VT_STEM_R4_128 was set: keep that band height at every batch size
 };
@@ -319,6 +321,10 @@ int check_ready(vt_model* m, int B) {
     return VT_OK;
 }
 
+// The batch size the kernel FORMS of a call are chosen by: the call's own, or the model's form batch (vt_set_form_batch) -- a shard
+// of a larger group of sequences then runs the forms the whole group would, so its results do not depend on how the group is sharded.
+int form_b(const vt_model* m, int B) { return std::max(B, m->form_batch); }
+
 // Band sizes per crop side.  stem_a: r2 layer-2 rows per workgroup (256 output pixels);
 // stem_b: r4 token rows per workgroup (LDS <= ~50 KB so three workgroups share a CU).
 struct StemPlan { int r2, r4; };
@@ -353,7 +359,8 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     const StemPlan pz{m->plan_r2[1], m->plan_r4[1]};
     // small batches of the 128-px search crop: stem_b in bands of 2 token rows (4 workgroups per crop instead of 2) shortens the
     // latency chain of a band (B=1 step 63.5 -> 59.9 us); at large batches the halo rows it recomputes cost more than that
-    if (Tx == 128 && B <= 80 && px.r4 == 4 && !m->r4_128_forced) px.r4 = 2;
+    const int Bf = form_b(m, B);
+    if (Tx == 128 && Bf <= 80 && px.r4 == 4 && !m->r4_128_forced) px.r4 = 2;
     for (const auto& pr : {std::make_pair(Tx, px), std::make_pair(Tz, pz)}) {
         const int T = pr.first, r2 = pr.second.r2, r4 = pr.second.r4;
         const int nt4 = r4 > 0 ? (r4 * (T / 16) + 15) / 16 : 0;
@@ -366,7 +373,7 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
 #ifndef VT_F16
     {   // the streaming form: one workgroup per frame, nothing but token rows leaves the CU
         const bool g256 = Tx == 256 && Tz == 128, g128 = Tx == 128 && Tz == 64;
-        const bool want_stream = m->stem_stream < 0 ? (g256 && B > 176) : m->stem_stream != 0;
+        const bool want_stream = m->stem_stream < 0 ? (g256 && Bf > 176) : m->stem_stream != 0;
         const bool diag = m->skip_stem_a != 0 || m->skip_stem_b != 0 || m->dbg_stamps != nullptr;
         if (want_stream && !diag && (g256 || g128)) {
             auto go = [&](auto kernel, size_t lds) {
@@ -390,8 +397,8 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         }
     }
 #endif
-    const bool want_fused = m->stem_fused < 0 ? B > 80 : m->stem_fused != 0;
-    const bool want_pipe = m->stem_pipe < 0 ? B > 176 : m->stem_pipe != 0;
+    const bool want_fused = m->stem_fused < 0 ? Bf > 80 : m->stem_fused != 0;
+    const bool want_pipe = m->stem_pipe < 0 ? Bf > 176 : m->stem_pipe != 0;
     if (want_fused && Tx == vts::FusedGeo::TX && Tz == vts::FusedGeo::TZ) {
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
         const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
@@ -402,7 +409,11 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_fused_kernel<0, true>);
-        else if (zmode == 0) go(&vts::stem_fused_kernel<0, false>);
+        else if (!m->stem_bf3) {      // VT_STEM_BF3=0: layer 3 on fp32 MFMAs (the all-fp32-MFMA step bench.py reports beside the default)
+            if (zmode == 0) go(&vts::stem_fused_kernel<0, false, false>);
+            else if (zmode == 1) go(&vts::stem_fused_kernel<1, false, false>);
+            else go(&vts::stem_fused_kernel<2, false, false>);
+        } else if (zmode == 0) go(&vts::stem_fused_kernel<0, false>);
         else if (zmode == 1) go(&vts::stem_fused_kernel<1, false>);
         else go(&vts::stem_fused_kernel<2, false>);
         HIP_TRY(hipGetLastError());
@@ -515,7 +526,8 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     const bool diag = m->dbg_skip_tile != -1 || m->dbg_stamps != nullptr;
     // measured (tools/small_batch_sweep.py, SWEEP_TILE=1; us per step, frame form -> tile form): G256 B=1 281 -> 86, B=32 300 -> 136,
     // B=64 314 -> 183, B=128 371 -> 315; G128 B=1 78 -> 59, B=16 79 -> 62, B=64 84 -> 83, B=80 88 -> 86, B=96 95 -> 95
-    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? B <= 128 : B <= 80) : m->blocks_tile != 0;
+    const int Bf = form_b(m, B);
+    const bool want_tile = m->blocks_tile < 0 ? (NTr == 20 ? Bf <= 128 : Bf <= 80) : m->blocks_tile != 0;
     if (want_tile && !diag && nblocks >= 1 && f0 + (size_t)B <= (size_t)m->tile_frames && (NTr == 5 || NTr == 20))
         return NTr == 5 ? launch_blocks_tile<5>(m, st, tokens, B, nblocks, feat, resid, zc, f0)
                         : launch_blocks_tile<20>(m, st, tokens, B, nblocks, feat, resid, zc, f0);
@@ -573,10 +585,11 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
     float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
+    const int Bf = form_b(m, B);
 #ifndef VT_F16
     if (m->F == 8 && m->head_bf3 && !m->skip_head) {       // three-piece bf16 towers (vt_head3.h), same kernel forms by batch size
         const vth3::u32x4* hw3 = reinterpret_cast<const vth3::u32x4*>(m->head3.p);
-        if (m->head_fused < 0 ? B > 176 : m->head_fused != 0) {
+        if (m->head_fused < 0 ? Bf > 176 : m->head_fused != 0) {
             hipLaunchKernelGGL(vth3::head_fused3_kernel, dim3(B), dim3(768), vth3::FUSED3_LDS_BYTES, st, feat, m->head.p, hw3, m->window.p,
                                score, size, offset, pred, hann, conf);
             HIP_TRY(hipGetLastError());
@@ -588,7 +601,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf, tail);
     }
 #endif
-    if (m->F == 8 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
+    if (m->F == 8 && (m->head_fused < 0 ? Bf > 176 : m->head_fused != 0)) {
         // towers + both decodes in one workgroup per frame
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(768), vth::FusedHeadGeo<8>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
@@ -606,7 +619,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         else
             hipLaunchKernelGGL((vth::head_towers_kernel<8, 4, false>), dim3(B, 3), dim3(256), vth::Geo<8>::LDS_BYTES, st, feat, m->head.p,
                                score, size, offset, m->skip_head);
-    } else if (m->F == 16 && (m->head_fused < 0 ? B > 176 : m->head_fused != 0)) {
+    } else if (m->F == 16 && (m->head_fused < 0 ? Bf > 176 : m->head_fused != 0)) {
         // one workgroup per frame: the three towers in turn on one staged input map, decode from LDS (no decode launch)
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(512), vth::SeqHeadGeo<16>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
@@ -617,7 +630,7 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         HIP_TRY(hipGetLastError());
         return VT_OK;       // (tail: on the kernel's decoding lane)
     } else if (m->F == 16 && !m->skip_head && B <= m->head_m1_frames && f0 == 0 &&
-               (m->head_split < 0 ? B <= HEAD_SPLIT_MAX_B : m->head_split != 0)) {
+               (m->head_split < 0 ? Bf <= HEAD_SPLIT_MAX_B : m->head_split != 0)) {
         // small batches: conv1 of every tower over four row strips (12 workgroups per frame), then the rest of each tower
         hipLaunchKernelGGL(vth::head_conv1_kernel<16>, dim3(4, 3, B), dim3(512), 0, st, feat, m->head.p, m->head_m1.p);
         hipLaunchKernelGGL((vth::head_towers_kernel<16, 8, false, true>), dim3(B, 3), dim3(512), vth::Geo<16>::LDS_BYTES, st,
@@ -700,6 +713,57 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ sr
     }
 }
 
+// ---- crop: which kernel form this device can run
+// crop_kernel<false> fetches a bilinear sample's two RGB pixels with ONE 8-byte buffer load at byte offset 3 x: it relies on the
+// device serving byte-unaligned dword loads and on out-of-range buffer reads returning zero (tools/src/probe_unaligned.hip).  Neither
+// is architectural, so the first vt_create of a process crops a known frame with both forms -- device memory and device-mapped pinned
+// host memory (the plugin's zero-copy frames) -- and falls back to the byte-load form on any difference (round 3 advisor).
+int g_crop_bytes = -1;        // -1: not tested yet, 0: fast form, 1: byte-load form
+
+void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const double* states, double factor, int T, const float* mean3,
+                 const float* std3, int B, hipStream_t st, float* crops, double* rf) {
+    dim3 grid((T * ((T + 3) / 4) + 255) / 256, B);
+    if (bytes)
+        hipLaunchKernelGGL(vtt::crop_kernel<true>, grid, dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0], mean3[1], mean3[2],
+                           std3[0], std3[1], std3[2], crops, rf);
+    else
+        hipLaunchKernelGGL(vtt::crop_kernel<false>, grid, dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0], mean3[1], mean3[2],
+                           std3[0], std3[1], std3[2], crops, rf);
+}
+
+int crop_selftest() {
+    if (g_crop_bytes >= 0) return VT_OK;
+    constexpr int H = 13, W = 17, T = 20, B = 2;          // odd sizes: windows at every byte alignment, crops across all four borders
+    std::vector<unsigned char> fr((size_t)B * H * W * 3);
+    for (size_t i = 0; i < fr.size(); ++i) fr[i] = (unsigned char)((i * 131u + (i >> 3) * 17u + 7u) & 0xffu);
+    const double st[B * 4] = {-2.5, -1.5, 9.0, 8.0, 9.5, 6.25, 9.0, 8.5};      // one box over the top-left corner, one over the bottom-right
+    const float mean3[3] = {0.485f, 0.456f, 0.406f}, std3[3] = {0.229f, 0.224f, 0.225f};
+    unsigned char *dfr = nullptr, *hfr = nullptr;
+    double *dst = nullptr, *drf = nullptr;
+    float* dout = nullptr;
+    const size_t nout = (size_t)B * 3 * T * T;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dfr), fr.size()));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hfr), fr.size(), hipHostMallocMapped));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), sizeof(st)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&drf), B * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), 3 * nout * sizeof(float)));
+    HIP_TRY(hipMemcpy(dfr, fr.data(), fr.size(), hipMemcpyHostToDevice));
+    std::memcpy(hfr, fr.data(), fr.size());
+    HIP_TRY(hipMemcpy(dst, st, sizeof(st), hipMemcpyHostToDevice));
+    launch_crop(true, dfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout, drf);                  // the reference form
+    launch_crop(false, dfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout + nout, drf);          // fast form, device memory
+    launch_crop(false, hfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout + 2 * nout, drf);      // fast form, pinned host memory
+    HIP_TRY(hipGetLastError());
+    std::vector<float> out(3 * nout);
+    HIP_TRY(hipMemcpy(out.data(), dout, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const bool same = std::memcmp(out.data(), out.data() + nout, nout * sizeof(float)) == 0 &&
+                      std::memcmp(out.data(), out.data() + 2 * nout, nout * sizeof(float)) == 0;
+    g_crop_bytes = same ? 0 : 1;
+    if (const char* v = std::getenv("VT_CROP_BYTES")) if (*v) g_crop_bytes = std::atoi(v) != 0;     // force a form (tests)
+    (void)hipFree(dfr); (void)hipHostFree(hfr); (void)hipFree(dst); (void)hipFree(drf); (void)hipFree(dout);
+    return VT_OK;
+}
+
 // ViT-Base model: the shared part of vt_model is the output scratch, the window and the capture stream
 int create_vitb(const vt_config* cfg, vt_model** out) {
     std::string err;
@@ -752,6 +816,9 @@ static hipError_t allow_stem_lds() {
     allow(&vts::stem_fused_kernel<1, false>, lf);
     allow(&vts::stem_fused_kernel<2, false>, lf);
     allow(&vts::stem_fused_kernel<0, true>, lf);
+    allow(&vts::stem_fused_kernel<0, false, false>, lf);
+    allow(&vts::stem_fused_kernel<1, false, false>, lf);
+    allow(&vts::stem_fused_kernel<2, false, false>, lf);
 #ifndef VT_F16
     allow(&vts::stem_stream_kernel<256, 128, 0>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
     allow(&vts::stem_stream_kernel<256, 128, 1>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
@@ -789,6 +856,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
                                         " B of LDS per workgroup at this geometry (limit " + std::to_string(LDS_PER_CU) + ")");
     }
 
+    if (int rcs = crop_selftest()) return rcs;
     vt_model* m = new vt_model();
     m->cfg = *cfg;
     m->F = cfg->search_size / 16;
@@ -841,6 +909,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_tile = env_int("VT_BLOCKS_TILE", -1);
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
+    m->stem_bf3 = env_int("VT_STEM_BF3", 1);
     {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
@@ -1114,6 +1183,13 @@ int vt_set_window(vt_model* m, const float* host_window) {
     return upload(m->window, std::vector<float>(host_window, host_window + (size_t)m->F * m->F));
 }
 
+int vt_set_form_batch(vt_model* m, int32_t n) {
+    if (!m) return fail(VT_ERR_ARG, "null model");
+    if (n < 0) return fail(VT_ERR_ARG, "vt_set_form_batch: n must be >= 0 (0 = choose the kernel forms by each call's own batch)");
+    m->form_batch = n;
+    return VT_OK;
+}
+
 int vt_query(const vt_model* m, int32_t* len_z, int32_t* len_x, int32_t* feat_sz, int32_t* channels) {
     if (!m) return fail(VT_ERR_ARG, "null model");
     if (len_z) *len_z = m->len_z;
@@ -1210,10 +1286,8 @@ int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const 
     if (!m || !frames_dev || !states_dev || !crops_dev || !resize_factor_dev || !mean3 || !std3)
         return fail(VT_ERR_ARG, "null argument");
     if (B < 1 || H < 1 || W < 1 || out_size < 1 || !(factor > 0.0)) return fail(VT_ERR_ARG, "bad crop arguments");
-    dim3 grid((out_size * ((out_size + 3) / 4) + 255) / 256, B);
-    hipLaunchKernelGGL(vtt::crop_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), frames_dev, H, W,
-                       states_dev, factor, out_size, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], crops_dev,
-                       resize_factor_dev);
+    launch_crop(g_crop_bytes == 1, frames_dev, H, W, states_dev, factor, out_size, mean3, std3, B, static_cast<hipStream_t>(stream), crops_dev,
+                resize_factor_dev);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }

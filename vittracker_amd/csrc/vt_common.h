@@ -42,7 +42,9 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
     for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, to_h4(b[n]), acc[n], 0, 0, 0);
 }
 #define VT_PRECISION_NAME "f16"
+constexpr bool VT_IS_F16 = true;
 #else
+constexpr bool VT_IS_F16 = false;
 __device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);

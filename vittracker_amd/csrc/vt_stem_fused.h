@@ -82,7 +82,9 @@ struct BandF {
 // ZMODE 0: both crops; 1: search crop only (the template's token rows are cached in `tokens`); 2: template only.
 // DIAG: the diagnostic build (VT_SKIP_* / VT_DBG_STAMPS); production instantiations compile `skip` and the stamps out -- as
 // run-time conditions they put every band's prefetched registers through a copy at each conditional call.
-template <int ZMODE, bool DIAG>
+// L3B (fp32 build; VT_STEM_BF3, default 1): layer 3 as exact three-piece bf16 products; false = on fp32 MFMAs, the form the f16 build
+// always runs (on its own MFMA).
+template <int ZMODE, bool DIAG, bool L3B = true>
 __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin,                       // (B,3,64,64), (B,3,128,128)
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w2k,                 // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
     const float* __restrict__ w3b) {               // layer-3 weights as three-piece bf16 images [out tile 2][chunk pair 4][piece 3][64 lanes][8 bf16] (f32 build)
     using G = FusedGeo;
+    constexpr bool L3BF3 = L3B && !VT_IS_F16;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
     const int skip = DIAG ? skip_arg : 0;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -352,23 +355,23 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     // layer-3 / layer-4 weights of this wave are requested while the pipeline's last interval runs /
     // while layer 3 runs, so their L2 round trips are not exposed
     constexpr int NCH4 = 14;
-#ifdef VT_F16
     constexpr int NCH3 = 7;
     const int ot3 = wave & 1;
     f4 w3a[NCH3][1];
-    auto load_w3 = [&]() { vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a); };
-#else
-    // layer 3 runs as three-piece bf16 products (vt_bf3.h): every wave needs the WHOLE image, so it goes through LDS.  Group B's
+    // L3BF3: layer 3 runs as three-piece bf16 products (vt_bf3.h): every wave needs the WHOLE image, so it goes through LDS.  Group B's
     // eight waves stage it (three LDS-DMA pieces each) in the interval in which they have nothing else to do.
     auto load_w3 = [&]() {
-        if (grp == 1) {
-            for (int t = gw; t < G::W3L_TILES; t += 8)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3b + (size_t)t * 256 + lane * 4),
-                                                 (__attribute__((address_space(3))) void*)(lds + G::W3L_OFF + t * 64), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (L3BF3) {
+            if (grp == 1) {
+                for (int t = gw; t < G::W3L_TILES; t += 8)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3b + (size_t)t * 256 + lane * 4),
+                                                     (__attribute__((address_space(3))) void*)(lds + G::W3L_OFF + t * 64), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a);
         }
     };
-#endif
     if (skip & 1) { load_w3(); __syncthreads(); }
     if (!(skip & 1)) {
         const bool l2 = !(skip & 2);
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             else if (e < 43) m3z[plane * G::NPIX3Z + (e - 34)] = splat4(0.f);
             else m3z[plane * G::NPIX3Z + (e - 43) * 9 + 4] = splat4(0.f);
         }
-#ifndef VT_F16
+        if constexpr (L3BF3) {
         // fp32 build: layer 3 as exact three-piece bf16 products.  The layer-2 maps stay fp32 (pre-split maps do not fit), so a B
         // operand is split where it is read -- which pays only if one split feeds BOTH output tiles: a wave takes one pixel tile
         // (x: map row `wave`; z: waves 0-3, 16 pixels each) and both tiles; 7 splits + 48 bf16 MFMAs per unit instead of 56 fp32
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                     }
             }
         }
-#else
+        } else {
         const f4 bv3 = ld4(cb3 + 16 * ot3 + 4 * q);
         if (!(skip & 4)) {
             if (do_x) {   // search: 16 pixel tiles (rows of the 16 x 16 map); this wave: rows wave>>1 and (wave>>1) + 8
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                 }
             }
         }
-#endif
+        }
     }
     stamp();
     __syncthreads();

@@ -51,7 +51,11 @@ struct StreamGeo {
     // instructions per chunk and lane, 21 chunks per interval on the waves that carry the interval's longest MFMA chains
     static constexpr int OFF3 = 8, OFF4 = 16;                                                // two 16-bit offsets per int: rows of 4 / 8 ints
     static constexpr int OFFTAB_F4 = (2 * 4 * OFF3 + 2 * 4 * OFF4) / 8;                      // 24
-    static constexpr int LDS_F4 = 2 * RING + 3 * SLOT2 + 3 * SLOT3 + round16(CONST_F4) + OFFTAB_F4;
+    // the LAST k-chunk of layer 4's weights (3 output tiles x 1 KiB) lives in LDS instead of registers: the layer-3/4 waves hold 84
+    // weight registers, and with all 14 chunks of layer 4 in registers the kernel needed 132-140 against the 128 a 1024-thread
+    // workgroup gets -- one weight quad was spilled and reloaded from scratch inside the interval loop, behind a vmcnt(0) (round 4)
+    static constexpr int W4L_F4 = 3 * 64;
+    static constexpr int LDS_F4 = 2 * RING + 3 * SLOT2 + 3 * SLOT3 + CONST_F4 + OFFTAB_F4 + W4L_F4;
     static constexpr int LDS_BYTES = LDS_F4 * 16;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert(r2(TX) % 4 == 0 && r2(TZ) % 4 == 0, "a band holds whole token rows");
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
     const float* const cb2 = reinterpret_cast<const float*>(cw2 + 9 * 32);            // 16 floats
     const float* const cb3 = cb2 + 16;                                                // 32
     const float* const cb4 = cb3 + 32;                                                // 48
-    int* const otab = reinterpret_cast<int*>(cw2 + round16(G::CONST_F4));             // [x | z][4][OFF3], then [x | z][4][OFF4]
+    int* const otab = reinterpret_cast<int*>(cw2 + G::CONST_F4);             // [x | z][4][OFF3], then [x | z][4][OFF4]
+    f4* const w4l = cw2 + G::CONST_F4 + G::OFFTAB_F4;                        // [3 output tiles][64 lanes]: layer 4's last k-chunk
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -286,9 +291,13 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
         const int w4 = wave - 12;
         constexpr int NCH3 = 7, NCH4 = 14;
         const int ot3 = w4 & 1;
-        f4 w3a[NCH3][1], w4a[NCH4][1];
+        constexpr int NR4 = NCH4 - 1;                  // layer-4 chunks held in registers; the last one is read from LDS (StreamGeo)
+        f4 w3a[NCH3][1], w4a[NR4][1];
         vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a);
-        if (w4 < 3) vtc::load_weights<1, NCH4, NCH4>(w4img + (size_t)w4 * NCH4 * 256, 0, NCH4, lane, w4a);
+        if (w4 < 3) {
+            vtc::load_weights<1, NR4, NCH4>(w4img + (size_t)w4 * NCH4 * 256, 0, NR4, lane, w4a);
+            w4l[w4 * 64 + lane] = ld4(w4img + ((size_t)w4 * NCH4 + NR4) * 256 + lane * 4);      // read back by this wave only
+        }
         auto layer3 = [&](const Band& J, int g) {
             const int ln = fresh(lane), q = ln >> 4, px = ln & 15, tid4 = w4 * 64 + ln;
             const f4* const in = l2ring + (g % 3) * G::SLOT2;
@@ -337,7 +346,6 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             const int y = px >> J.lgW4, x = px & ((1 << J.lgW4) - 1);          // the band's 16 tokens = one tile
             const int base = 2 * y * J.pitch3 + x;
             const int tk = 16 * J.kb + px;                                      // token index inside this crop
-            const f4 pe = ld4((J.is_z ? pos_z : pos_x) + (size_t)tk * 48 + 16 * w4 + 4 * q);   // requested before the MFMAs
             const int4* const tp4 = reinterpret_cast<const int4*>(otab + 4 * G::OFF3 + (J.is_z ? 2 * G::OFF4 : 0) + q * (G::OFF4 / 2));
             const int4 o4a = tp4[0], o4b = tp4[1];
             auto at = [&](int c) {
@@ -351,19 +359,31 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             static_assert(NCH4 % 2 == 0, "chunk pairs");
             f4 acc0 = ld4(cb4 + 16 * w4 + 4 * q), acc1 = splat4(0.f);
             f4 b0 = in[at(0)], b1 = in[at(1)];
+            f4 pe = acc1;
 #pragma unroll
             for (int k = 0; k < NCH4; k += 2) {
-                f4 n0 = b0, n1 = b1;
                 if (k + 2 < NCH4) {
-                    n0 = in[at(k + 2)]; n1 = in[at(k + 3)];
+                    const f4 n0 = in[at(k + 2)], n1 = in[at(k + 3)];
+                    // the pos-embed row is requested three pairs (~770 cycles of MFMAs) before it is added, not at the top: with it, the
+                    // last chunk's weights and two operand pairs live together this role needed more than its 128 registers
+                    if (k + 6 == NCH4) pe = ld4((J.is_z ? pos_z : pos_x) + (size_t)tk * 48 + 16 * w4 + 4 * q);
                     __builtin_amdgcn_sched_barrier(0);        // keep the next pair's reads ahead of this pair's MFMAs
-                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4a[k][0][r], b0[r], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4a[k + 1][0][r], b1[r], acc1, 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4a[k][0][r], b0[r], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4a[k + 1 < NR4 ? k + 1 : 0][0][r], b1[r], acc1, 0, 0, 0);
+                    }
+                    b0 = n0; b1 = n1;
+                } else {
+                    // last pair: chunk NCH4 - 1's weights come from LDS (StreamGeo), requested here -- no operand prefetch is live any
+                    // more -- and covered by the even chunk's four MFMAs
+                    const f4 wlast = w4l[w4 * 64 + ln];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4a[k][0][r], b0[r], acc0, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wlast[r], b1[r], acc1, 0, 0, 0);
                 }
-                b0 = n0; b1 = n1;
             }
             st4(tokens + ((size_t)b * L + (J.is_z ? 0 : len_z) + tk) * 48 + 16 * w4 + 4 * q, (acc0 + acc1) + pe);
         };

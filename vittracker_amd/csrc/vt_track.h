@@ -38,6 +38,9 @@ __device__ __forceinline__ void lin_coeff(int d, int src, double scale, int& s0,
 // One thread = four consecutive output pixels of a row (all three channels): the vertical coefficients are computed once,
 // and a channel's four values leave as ONE 16-byte store when T is a multiple of 4 (the crop sizes the tracker uses are:
 // 64 / 128 / 256), i.e. whole 256-byte row segments per quarter-wave instead of 4-byte stores.
+// BYTES = true: the same kernel with every 8-byte window assembled from eight single-byte loads -- the form that needs nothing of the
+// device's unaligned-access mode; vt_create's self test (vittrack.hip: crop_selftest) selects it when the fast form's result differs.
+template <bool BYTES = false>
 __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restrict__ frames, int H, int W,
                                                    const double* __restrict__ states, double factor, int T,
                                                    float m0, float m1, float m2, float s0, float s1, float s2,
@@ -107,6 +110,13 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     const unsigned rowo0 = (unsigned)(vr0 ? yy0 : 0) * (unsigned)(W * 3), rowo1 = (unsigned)(vr1 ? yy1 : 0) * (unsigned)(W * 3);
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
     auto load8 = [&](unsigned off) -> unsigned long long {      // bytes off .. off + 7 of the frame (the last bytes of the batch: shifted in)
+        if constexpr (BYTES) {
+            unsigned long long r = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)       // out-of-range bytes read as zero (buffer bounds), as in the fast form after its shift
+                r |= (unsigned long long)(__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)(off + j), 0, 0) & 0xffu) << (8 * j);
+            return r;
+        }
         const unsigned over = off + 8u > nrec ? off + 8u - nrec : 0u;
         const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off - over), 0, 0);
         return (((unsigned long long)v.y << 32) | v.x) >> (8u * over);

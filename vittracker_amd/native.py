@@ -24,7 +24,7 @@ SYMBOLS = [
     "vt_last_error", "vt_version", "vt_create", "vt_destroy", "vt_load_weights", "vt_set_window",
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
-    "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record", "vt_track_step",
+    "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record", "vt_track_step", "vt_set_form_batch",
 ]
 
 
@@ -93,6 +93,7 @@ def lib(precision: str = "f32"):
     L.vt_update_state.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.vt_update_state_record.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.vt_set_template.argtypes = [vp, vp, i32, vp]
+    L.vt_set_form_batch.argtypes = [vp, i32]
     L.vt_track_step.argtypes = [vp, vp, i32, i32, vp, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp, vp, i32, vp]
     if precision == "f32":
         _lib = L
@@ -254,6 +255,12 @@ class Model:
             arr[n] = VtTensor(k.encode(), a.ctypes.data, a.size)
             n += 1
         _check(self._L.vt_load_weights(self._h, arr, n), "vt_load_weights", self._L)
+
+    def set_form_batch(self, n: int):
+        """Choose the kernel forms as for a batch of n sequences (vt_set_form_batch): a shard of a group of n runs the forms the whole
+        group would run, so a sequence's results do not depend on how the group is sharded.  0 = by each call's own batch."""
+        _check(self._L.vt_set_form_batch(self._h, int(n)), "vt_set_form_batch", self._L)
+        self.form_batch = int(n)
 
     def set_window(self, win):
         a = np.ascontiguousarray(np.asarray(win, dtype=np.float32).reshape(-1))
