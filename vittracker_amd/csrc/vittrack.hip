@@ -764,6 +764,14 @@ int crop_selftest() {
     return VT_OK;
 }
 
+#ifdef VT_F16
+// float4 -> h4 (the MFMA operand conversion of vt_common.h), n4 quads
+__global__ void f32_to_opnd_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) reinterpret_cast<opnd*>(dst)[i] = to_opnd(ld4(src + 4 * i));
+}
+#endif
+
 // ViT-Base model: the shared part of vt_model is the output scratch, the window and the capture stream
 int create_vitb(const vt_config* cfg, vt_model** out) {
     std::string err;
@@ -1130,11 +1138,25 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + C, p, C * sizeof(float));
     }
     if ((rc = upload(m->blocks, bp))) return rc;
+#ifdef VT_F16
+    {   // f16 build: the block kernels read their weight images as stored operands (vt_common.h `opnd` = h4) -- converted ONCE here,
+        // on the device, by the conversion the kernels applied at every MFMA call before (bit-identical results); BLOCK_STRIDE halves
+        // per block at the float layout's offsets, + 1 KiB of slack behind the last image (the staging DMA moves whole KiB)
+        const size_t nflt = (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;
+        m->blocks3.release();
+        if ((rc = m->blocks3.alloc(nflt / 2 + 256 + 256))) return rc;
+        hipLaunchKernelGGL(f32_to_opnd_kernel, dim3((unsigned)((nflt / 4 + 255) / 256)), dim3(256), 0, nullptr, m->blocks.p,
+                           reinterpret_cast<_Float16*>(m->blocks3.p), nflt / 4);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+#else
     {
         std::vector<float> as_f(bp3.size() / 2);
         std::memcpy(as_f.data(), bp3.data(), bp3.size() * 2);
         if ((rc = upload(m->blocks3, as_f))) return rc;
     }
+#endif
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
 #ifndef VT_F16

@@ -92,6 +92,9 @@ __device__ __forceinline__ f4 wimg(const float* __restrict__ base, int tile, int
     return ld4(base + (size_t)tile * 256 + lane * 4);
 }
 
+// the same from an image of stored operands (vt_common.h `opnd`: f4, or the f16 build's pre-converted h4 images)
+__device__ __forceinline__ opnd wimg_o(const opnd* __restrict__ base, int tile, int lane) { return base[(size_t)tile * 64 + lane]; }
+
 // Burst-load N weight operand images (tile indices first + j * stride) and pin the burst where it
 // is written, so it is in flight while the code that follows (LayerNorm, the previous GEMM's MFMAs)
 // executes instead of stalling the GEMM that consumes it.
@@ -186,12 +189,13 @@ __device__ __forceinline__ void stage_tiles(f4* dst, const float* __restrict__ s
 // chunk c+1 are requested BEFORE the MFMAs of chunk c are issued (explicit double buffer): left to
 // itself the scheduler puts each ds_read / global_load right in front of its first use and the wave
 // pays the full read latency once per chunk (measured: ~47 instead of 32 cycles per MFMA).
-template <int NCHUNK, int N, bool SHARED_IS_B, bool PRELOAD_ALL = true, typename OpA, typename OpS>
+// AT: type of the per-chain operands: `opnd` for stored images (weights, K, V^T), f4 for values computed in this wave.
+template <int NCHUNK, int N, bool SHARED_IS_B, bool PRELOAD_ALL = true, typename AT = opnd, typename OpA, typename OpS>
 __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
     if constexpr (PRELOAD_ALL && NCHUNK * N <= 24) {
         // small stage: request every operand first and pin the requests ahead of the MFMAs -- one
         // read round trip per stage instead of one per chunk
-        f4 a[NCHUNK][N];
+        AT a[NCHUNK][N];
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) opa(c, a[c]);
         __builtin_amdgcn_sched_barrier(0);
@@ -201,7 +205,7 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
             else mfma4_shared_a(ops(c), a[c], acc);
         }
     } else {
-        f4 a[2][N];
+        AT a[2][N];
         opa(0, a[0]);
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
@@ -250,8 +254,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
     constexpr int GT = NT - 1;                             // BAL: the guests' tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]
+    f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]   (BF3L: also fc2's third output tile, as pieces)
     f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
+    // the K and V^T images as STORED operands (f16 build: h4, half the bytes of the same area; written once per block, read by every wave)
+    opnd* const Ko = reinterpret_cast<opnd*>(Kimg);
+    opnd* const Vo = reinterpret_cast<opnd*>(Vimg);
     f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
     constexpr int WA_TILES = BF3L ? W3_FC1_TILES : WBUF_TILES;      // BF3: fc1's three-piece image is 54 KiB
     f4* Wb = Wa + WA_TILES * 64;                           // WLDS: [36][64] staging buffer B (BF3: fc2's output tiles 0 and 1; tile 2 goes to the K / V area, free during the MLP)
@@ -285,8 +292,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     };
     auto fstamp = [&]() { if (fine) stamp(); };     // per-stage stamps (VT_DBG_STAMPS=2)
     stamp();
+    // staging of an image of `ntiles` stored-operand tiles of block `blk_of` into an LDS buffer, as 1 KiB DMA pieces (fp32 build:
+    // one per float4 tile of `params`; f16 build: one per TWO h4 tiles of the pre-converted images in `params3`, BLOCK_STRIDE halves
+    // per block at the float layout's offsets -- an odd tile count reads 512 bytes past the image, inside the buffer)
+    auto stage_img = [&](f4* dst, int off, int ntiles, int blk_of) {
+        if constexpr (VT_IS_F16)
+            stage_tiles(dst, reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(params3) + (size_t)blk_of * BLOCK_STRIDE + off), (ntiles + 1) / 2, w, NW, lane);
+        else
+            stage_tiles(dst, params + (size_t)blk_of * BLOCK_STRIDE + off, ntiles, w, NW, lane);
+    };
     if constexpr (BF3L) stage_tiles(Wa, params3 + (W3_FC1_TILES + W3_FC2_TILES) * 256, W3_QKV_TILES, w, NW, lane);
-    else if constexpr (WLDS) stage_tiles(Wa, params + O_WQKV, 9 * NC, w, NW, lane);   // block 0's qkv weights
+    else if constexpr (WLDS) stage_img(Wa, O_WQKV, 9 * NC, 0);   // block 0's qkv weights
     for (int i = threadIdx.x; 4 * i < small_floats(depth_total); i += NW * 64)
         st4(Sp + 4 * i, ld4(params + small_src(4 * i, depth_total)));
 
@@ -325,10 +341,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         const float* __restrict__ P = params + (size_t)blk * BLOCK_STRIDE;
         const float* S = Sp + blk * SMALL_STRIDE;
         // weight operand image `t` of each GEMM: from the staging buffers (WLDS) or straight from L2
-        auto w_qkv = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_WQKV, t, lane); };
-        auto w_proj = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_WPROJ, t, lane); };
-        auto w_fc1 = [&](int t) { return WLDS ? Wa[t * 64 + lane] : wimg(P + O_W1, t, lane); };
-        auto w_fc2 = [&](int t) { return WLDS ? Wb[t * 64 + lane] : wimg(P + O_W2, t, lane); };
+        // (stored operands, vt_common.h `opnd`: the fp32 build reads the float4 images of `params`; the f16 build the same images
+        // converted once at vt_load_weights -- `params3` then holds them, BLOCK_STRIDE halves per block at the float layout's offsets)
+        const opnd* const Po = VT_IS_F16 ? reinterpret_cast<const opnd*>(reinterpret_cast<const _Float16*>(params3) + (size_t)blk * BLOCK_STRIDE)
+                                         : reinterpret_cast<const opnd*>(P);
+        const opnd* const Wa_o = reinterpret_cast<const opnd*>(Wa);
+        const opnd* const Wb_o = reinterpret_cast<const opnd*>(Wb);
+        auto w_qkv = [&](int t) { return WLDS ? Wa_o[t * 64 + lane] : wimg_o(Po + O_WQKV / 4, t, lane); };
+        auto w_proj = [&](int t) { return WLDS ? Wb_o[t * 64 + lane] : wimg_o(Po + O_WPROJ / 4, t, lane); };
+        auto w_fc1 = [&](int t) { return WLDS ? Wa_o[t * 64 + lane] : wimg_o(Po + O_W1 / 4, t, lane); };
+        auto w_fc2 = [&](int t) { return WLDS ? Wb_o[t * 64 + lane] : wimg_o(Po + O_W2 / 4, t, lane); };
         // BF3 staging: the same four bursts per block as the fp32 form, issued by all eight waves at the start of the phase before the
         // one that reads them (fc1 54 KiB -> Wa during attention; fc2 36 KiB -> Wb + 18 KiB -> the K / V area during the fc1 phase).
         // The bursts cost ~1.3 us per launch (VT_BLK_NOSTAGE = 2); every other placement measured slower or equal.
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         };
         if constexpr (BF3L) {
             stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane, blk == 0);
-        } else if constexpr (WLDS) stage_tiles(Wb, P + O_WPROJ, NC * NC, w, NW, lane);   // proj: free since the last barrier
+        } else if constexpr (WLDS) stage_img(Wb, O_WPROJ, NC * NC, blk);   // proj: free since the last barrier
 
         f4 qr[TPW][NC];
         // ---- LN1 + QKV; publish K / V^T images ------------------------------------------------
@@ -399,8 +421,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
                     qr[i][ot] = zc[ot * 64];
-                    Kimg[(T * NC + ot) * 64 + lane] = zc[(NC + ot) * 64];
-                    Vimg[(ot * NT + T) * 64 + lane] = zc[(2 * NC + ot) * 64];
+                    Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
+                    Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
                 }
             } else if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
@@ -444,8 +466,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         if (t < 2 * NC) r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
                         else r = tile48(std::true_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
                         if (t < NC) qr[i][ot] = r;
-                        else if (t < 2 * NC) Kimg[(T * NC + ot) * 64 + lane] = r;
-                        else Vimg[(ot * NT + T) * 64 + lane] = r;
+                        else if (t < 2 * NC) Ko[(T * NC + ot) * 64 + lane] = to_opnd(r);
+                        else Vo[(ot * NT + T) * 64 + lane] = to_opnd(r);
                         if (z_tile && zcache_mode == 1) zc[t * 64] = r;
                         if (t == 2 * NC - 1) fstamp();
                     }
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(S + S_BQKV + 16 * ot + 4 * q);
                     gemm_stage<NC, 2 * NC, true, WLDS>(
-                        [&](int c, f4 (&a)[2 * NC]) {
+                        [&](int c, opnd (&a)[2 * NC]) {
 #pragma unroll
                             for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = w_qkv(ot * NC + c);
                         },
@@ -463,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) {
                         qr[i][ot] = acc[ot];
-                        Kimg[(T * NC + ot) * 64 + lane] = acc[NC + ot];
+                        Ko[(T * NC + ot) * 64 + lane] = to_opnd(acc[NC + ot]);
                         if (z_tile && zcache_mode == 1) { zc[ot * 64] = acc[ot]; zc[(NC + ot) * 64] = acc[NC + ot]; }
                     }
                 }
@@ -473,14 +495,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
                     gemm_stage<NC, NC, false, WLDS>(
-                        [&](int c, f4 (&bw)[NC]) {
+                        [&](int c, opnd (&bw)[NC]) {
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) bw[ot] = w_qkv((2 * NC + ot) * NC + c);
                         },
                         [&](int c) { return h[c]; }, acc);
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) {
-                        Vimg[(ot * NT + T) * 64 + lane] = acc[ot];
+                        Vo[(ot * NT + T) * 64 + lane] = to_opnd(acc[ot]);
                         if (z_tile && zcache_mode == 1) zc[(2 * NC + ot) * 64] = acc[ot];
                     }
                 }
@@ -506,9 +528,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < NC; ++j) r[j] = tile48(std::false_type{}, a0[j], a2[j], hb, hc, bias[j]);
-                    f4* dst = g == 0 ? Qg : Kimg + GT * NC * 64;
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) dst[j * 64 + lane] = r[j];
+                    for (int j = 0; j < NC; ++j) {
+                        if (g == 0) Qg[j * 64 + lane] = r[j];
+                        else Ko[(GT * NC + j) * 64 + lane] = to_opnd(r[j]);
+                    }
                 } else {
                     f4 bias[NC];
 #pragma unroll
@@ -517,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < NC; ++j) r[j] = tile48(std::true_type{}, a0[j], a2[j], hb, hc, bias[j]);
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) Vimg[(j * NT + GT) * 64 + lane] = r[j];
+                    for (int j = 0; j < NC; ++j) Vo[(j * NT + GT) * 64 + lane] = to_opnd(r[j]);
                 }
             } else if (VT_BLK_GUESTS && w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
                 f4 h[NC];
@@ -527,25 +551,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) acc[ot] = ld4(S + S_BQKV + 16 * (g * NC + ot) + 4 * q);
                     gemm_stage<NC, NC, true, true>(
-                        [&](int c, f4 (&a)[NC]) {
+                        [&](int c, opnd (&a)[NC]) {
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) a[ot] = w_qkv((g * NC + ot) * NC + c);
                         },
                         [&](int c) { return h[c]; }, acc);
-                    f4* dst = g == 0 ? Qg : Kimg + GT * NC * 64;
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) dst[ot * 64 + lane] = acc[ot];
+                    for (int ot = 0; ot < NC; ++ot) {
+                        if (g == 0) Qg[ot * 64 + lane] = acc[ot];
+                        else Ko[(GT * NC + ot) * 64 + lane] = to_opnd(acc[ot]);
+                    }
                 } else {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(S[S_BQKV + 2 * C + 16 * ot + tok]);
                     gemm_stage<NC, NC, false, true>(
-                        [&](int c, f4 (&bw)[NC]) {
+                        [&](int c, opnd (&bw)[NC]) {
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) bw[ot] = w_qkv((2 * NC + ot) * NC + c);
                         },
                         [&](int c) { return h[c]; }, acc);
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) Vimg[(ot * NT + GT) * 64 + lane] = acc[ot];
+                    for (int ot = 0; ot < NC; ++ot) Vo[(ot * NT + GT) * 64 + lane] = to_opnd(acc[ot]);
                 }
             }
         }
@@ -554,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         stamp();
         if constexpr (BF3L) {
             stage_tiles(Wa, P3, W3_FC1_TILES, w, NW, lane, blk == 0);
-        } else if constexpr (WLDS) stage_tiles(Wa, P + O_W1, NH * NC, w, NW, lane);      // fc1 weights
+        } else if constexpr (WLDS) stage_img(Wa, O_W1, NH * NC, blk);      // fc1 weights
         // In the last block the template rows only matter as keys / values: their attention
         // output, proj and MLP never reach the head (vit_dist.py:126 keeps the search rows only),
         // so those tiles stop after publishing K / V -- unless the caller asked for the residual.
@@ -577,9 +603,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < JG; ++j) acc[j] = splat4(0.f);
                     gemm_stage<NC, JG, true, WLDS>(
-                        [&](int c, f4 (&a)[JG]) {
+                        [&](int c, opnd (&a)[JG]) {
 #pragma unroll
-                            for (int j = 0; j < JG; ++j) a[j] = Kimg[((j0 + j) * NC + c) * 64 + lane];
+                            for (int j = 0; j < JG; ++j) a[j] = Ko[((j0 + j) * NC + c) * 64 + lane];
                         },
                         [&](int c) { return qr[i][c]; }, acc);
 #pragma unroll
@@ -611,9 +637,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
                 gemm_stage<NT, NC, true, WLDS>(                // O^T = V^T P^T: 3 feature-tile chains share B = P_J
-                    [&](int J, f4 (&a)[NC]) {
+                    [&](int J, opnd (&a)[NC]) {
 #pragma unroll
-                        for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J) * 64 + lane];
+                        for (int t = 0; t < NC; ++t) a[t] = Vo[(t * NT + J) * 64 + lane];
                     },
                     [&](int J) { return s[J]; }, o);
 #pragma unroll
@@ -622,7 +648,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q);
                 gemm_stage<NC, NC, true, WLDS>(
-                    [&](int c, f4 (&a)[NC]) {
+                    [&](int c, opnd (&a)[NC]) {
 #pragma unroll
                         for (int ot = 0; ot < NC; ++ot) a[ot] = w_proj(ot * NC + c);
                     },
@@ -641,9 +667,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) sc[j] = splat4(0.f);
                     gemm_stage<NC, NJ, true, true>(
-                        [&](int c, f4 (&a)[NJ]) {
+                        [&](int c, opnd (&a)[NJ]) {
 #pragma unroll
-                            for (int j = 0; j < NJ; ++j) a[j] = Kimg[((J0 + j) * NC + c) * 64 + lane];
+                            for (int j = 0; j < NJ; ++j) a[j] = Ko[((J0 + j) * NC + c) * 64 + lane];
                         },
                         [&](int c) { return qv[c]; }, sc);
                     float m0 = -3.0e38f, m1 = -3.0e38f;          // raw scores, as in the owners' path
@@ -673,9 +699,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
                     gemm_stage<NJ, NC, true, true>(
-                        [&](int J, f4 (&a)[NC]) {
+                        [&](int J, opnd (&a)[NC]) {
 #pragma unroll
-                            for (int t = 0; t < NC; ++t) a[t] = Vimg[(t * NT + J0 + J) * 64 + lane];
+                            for (int t = 0; t < NC; ++t) a[t] = Vo[(t * NT + J0 + J) * 64 + lane];
                         },
                         [&](int J) { return sc[J]; }, o);
 #pragma unroll
@@ -715,7 +741,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rl);
                     f4 acc[1] = {splat4(0.f)};
-                    gemm_stage<NC, 1, true, true>([&](int c, f4 (&a)[1]) { a[0] = w_proj(g * NC + c); },
+                    gemm_stage<NC, 1, true, true>([&](int c, opnd (&a)[1]) { a[0] = w_proj(g * NC + c); },
                                                   [&](int c) { return o[c]; }, acc);
                     Dg[g * 64 + lane] = acc[0];
                 }
@@ -727,7 +753,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         if constexpr (BF3L) {
             stage_tiles(Wb, P3 + W3_FC1_TILES * 256, WBUF_TILES, w, NW, lane, blk == 0);                                          // fc2, output tiles 0 and 1
             stage_tiles(Kimg, P3 + (W3_FC1_TILES + WBUF_TILES) * 256, W3_FC2_TILES - WBUF_TILES, w, NW, lane, blk == 0);           // output tile 2
-        } else if constexpr (WLDS) stage_tiles(Wb, P + O_W2, NC * NH, w, NW, lane);      // fc2 weights
+        } else if constexpr (WLDS) stage_img(Wb, O_W2, NC * NH, blk);      // fc2 weights
         // ---- LN2 + MLP (residual add) ---------------------------------------------------------
         // fc1 -> GELU -> fc2 in three groups of HG = 4 hidden tiles, software-pipelined so GELU (VALU)
         // of one group issues in the shadow of the next group's MFMAs:
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
             for (int j = 0; j < HG; ++j) acc[j] = ld4(S + S_B1 + 16 * (HG * g + j) + 4 * q);
             gemm_stage<NC, HG, true, WLDS>(
-                [&](int c, f4 (&a)[HG]) {
+                [&](int c, opnd (&a)[HG]) {
 #pragma unroll
                     for (int j = 0; j < HG; ++j) a[j] = w_fc1((HG * g + j) * NC + c);
                 },
@@ -754,7 +780,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
         };
         auto fc2 = [&](const f4 (&hd)[NH], int g, f4 (&xo)[NC]) {
             gemm_stage<HG, NC, true, WLDS>(
-                [&](int cc, f4 (&a)[NC]) {
+                [&](int cc, opnd (&a)[NC]) {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + HG * g + cc);
                 },
@@ -1036,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < NC; ++j) ghid[j] = ld4(S + S_B1 + 16 * (NC * g + j) + 4 * q);
                     gemm_stage<NC, NC, true, true>(
-                        [&](int c, f4 (&a)[NC]) {
+                        [&](int c, opnd (&a)[NC]) {
 #pragma unroll
                             for (int j = 0; j < NC; ++j) a[j] = w_fc1((NC * g + j) * NC + c);
                         },
@@ -1048,7 +1074,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
             stamp();            // fc1 done
             barrier_publish<WLDS>();    // fc2 weights landed; buffer A free
-            if (blk + 1 < nblocks) stage_tiles(Wa, P + BLOCK_STRIDE + O_WQKV, 9 * NC, w, NW, lane);   // next block's qkv
+            if (blk + 1 < nblocks) stage_img(Wa, O_WQKV, 9 * NC, blk + 1);   // next block's qkv
             stamp();
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -1061,7 +1087,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
                     gemm_stage<NC, NC, true, true>(
-                        [&](int cc, f4 (&a)[NC]) {
+                        [&](int cc, opnd (&a)[NC]) {
 #pragma unroll
                             for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + NC * g + cc);
                         },
@@ -1152,7 +1178,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         for (int j = 0; j < G6; ++j) acc[j] = ld4(S + S_B1 + 16 * (g + j) + 4 * q);
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {
-                            f4 a[G6];
+                            opnd a[G6];
 #pragma unroll
                             for (int j = 0; j < G6; ++j) a[j] = w_fc1((g + j) * NC + c);
                             mfma4_shared_b(a, h[c], acc);
@@ -1165,7 +1191,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     for (int ot = 0; ot < NC; ++ot) x[i][ot] = x[i][ot] + ld4(S + S_B2 + 16 * ot + 4 * q);
 #pragma unroll
                     for (int c = 0; c < NH; ++c) {
-                        f4 a[NC];
+                        opnd a[NC];
 #pragma unroll
                         for (int ot = 0; ot < NC; ++ot) a[ot] = w_fc2(ot * NH + c);
                         mfma4_shared_b(a, hd[c], x[i]);

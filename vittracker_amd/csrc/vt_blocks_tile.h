@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void tile_qkv_kernel(const float* __restrict__ 
         f4 acc[2 * NC];
 #pragma unroll
         for (int ot = 0; ot < 2 * NC; ++ot) acc[ot] = ld4(P + O_BQKV + 16 * ot + 4 * q);
-        gemm_stage<NC, 2 * NC, true, false>(
+        gemm_stage<NC, 2 * NC, true, false, f4>(
             [&](int c, f4 (&a)[2 * NC]) {
 #pragma unroll
                 for (int ot = 0; ot < 2 * NC; ++ot) a[ot] = wimg(P + O_WQKV, ot * NC + c, lane);
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void tile_qkv_kernel(const float* __restrict__ 
         f4 acc[NC];
 #pragma unroll
         for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(P[O_BQKV + 2 * C + 16 * ot + tok]);
-        gemm_stage<NC, NC, false, false>(
+        gemm_stage<NC, NC, false, false, f4>(
             [&](int c, f4 (&bw)[NC]) {
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) bw[ot] = wimg(P + O_WQKV, (2 * NC + ot) * NC + c, lane);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         f4 sc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) sc[j] = splat4(0.f);
-        gemm_stage<NC, NJ, true, false>(
+        gemm_stage<NC, NJ, true, false, f4>(
             [&](int c, f4 (&a)[NJ]) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) a[j] = kf[((J0 + j) * NC + c) * 64];
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         f4 o[NC];
 #pragma unroll
         for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
-        gemm_stage<NJ, NC, true, false>(
+        gemm_stage<NJ, NC, true, false, f4>(
             [&](int J, f4 (&a)[NC]) {
 #pragma unroll
                 for (int t = 0; t < NC; ++t) a[t] = vf[(t * NT + J0 + J) * 64];
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
     // ---- proj: output tile g (waves 0..2) -> LDS; everybody adds all three
     if (g < NC) {
         f4 acc[1] = {splat4(0.f)};
-        gemm_stage<NC, 1, true, false>([&](int c, f4 (&a)[1]) { a[0] = wimg(P + O_WPROJ, g * NC + c, lane); },
+        gemm_stage<NC, 1, true, false, f4>([&](int c, f4 (&a)[1]) { a[0] = wimg(P + O_WPROJ, g * NC + c, lane); },
                                        [&](int c) { return o[c]; }, acc);
         Dg[g * 64 + lane] = acc[0];
     }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         f4 hd[HPW];
 #pragma unroll
         for (int j = 0; j < HPW; ++j) hd[j] = ld4(P + O_B1 + 16 * (HPW * g + j) + 4 * q);
-        gemm_stage<NC, HPW, true, false>(
+        gemm_stage<NC, HPW, true, false, f4>(
             [&](int c, f4 (&a)[HPW]) {
 #pragma unroll
                 for (int j = 0; j < HPW; ++j) a[j] = wimg(P + O_W1, (HPW * g + j) * NC + c, lane);
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         f4 part[NC];
 #pragma unroll
         for (int ot = 0; ot < NC; ++ot) part[ot] = splat4(0.f);
-        gemm_stage<HPW, NC, true, false>(
+        gemm_stage<HPW, NC, true, false, f4>(
             [&](int cc, f4 (&a)[NC]) {
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(P + O_W2, ot * NH + HPW * g + cc, lane);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         if (g < 2) {
 #pragma unroll
             for (int ot = 0; ot < NC; ++ot) acc[ot] = ld4(Pn + O_BQKV + 16 * (g * NC + ot) + 4 * q);
-            gemm_stage<NC, NC, true, false>(
+            gemm_stage<NC, NC, true, false, f4>(
                 [&](int c, f4 (&a)[NC]) {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) a[ot] = wimg(Pn + O_WQKV, (g * NC + ot) * NC + c, lane);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void tile_attn_mlp_kernel(const float* __restr
         } else {
 #pragma unroll
             for (int ot = 0; ot < NC; ++ot) acc[ot] = splat4(Pn[O_BQKV + 2 * C + 16 * ot + tok]);
-            gemm_stage<NC, NC, false, false>(
+            gemm_stage<NC, NC, false, false, f4>(
                 [&](int c, f4 (&bw)[NC]) {
 #pragma unroll
                     for (int ot = 0; ot < NC; ++ot) bw[ot] = wimg(Pn + O_WQKV, (2 * NC + ot) * NC + c, lane);

@@ -41,6 +41,24 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, to_h4(b[n]), acc[n], 0, 0, 0);
 }
+// Stored operand images (round 4): an operand that is written once and read many times -- weight images, the K / V^T images of the
+// block kernel -- is kept in the MFMA's own operand type, so the f16 build converts it ONCE where it is produced (weights: at
+// vt_load_weights, on the device, by this same conversion) instead of at every MFMA call; the values are the same (RNE of the same
+// fp32 number), the results bit-identical.  The fp32 build stores float4 and `opnd` is f4.
+typedef h4 opnd;
+__device__ __forceinline__ opnd to_opnd(f4 v) { return to_h4(v); }
+template <int N>
+__device__ __forceinline__ void mfma4_shared_b(const h4 (&a)[N], f4 b, f4 (&acc)[N]) {
+    const h4 hb = to_h4(b);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[n], hb, acc[n], 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void mfma4_shared_a(f4 a, const h4 (&b)[N], f4 (&acc)[N]) {
+    const h4 ha = to_h4(a);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, b[n], acc[n], 0, 0, 0);
+}
 #define VT_PRECISION_NAME "f16"
 constexpr bool VT_IS_F16 = true;
 #else
@@ -71,6 +89,8 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
 #pragma unroll
         for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[n][r], acc[n], 0, 0, 0);
 }
+typedef f4 opnd;
+__device__ __forceinline__ opnd to_opnd(f4 v) { return v; }
 #define VT_PRECISION_NAME "f32"
 #endif
 
