@@ -68,6 +68,7 @@ struct vt_model {
     // parameters on the device
     DevBuf stem_w[4], stem_b[4];     // folded, [group][tap][cin][OCG] / [cout]
     DevBuf stem_w3b;                 // layer 3 as three-piece bf16 images (stem_fused, fp32 build)
+    DevBuf stem_w4b;                 // layer 4, the same way: [out tile 3][chunk pair 7][piece 3][64 lanes][8 bf16]
     DevBuf stem_w2k;                 // layer 2 again as [tap][input-channel quad][16 output channels][4] for the 4-block f32 MFMA
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
@@ -403,9 +404,9 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
         const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES_P, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
                                m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p,
-                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p, m->stem_w3b.p);
+                               m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p, m->stem_w3b.p, m->stem_w4b.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_fused_kernel<0, true>);
@@ -815,7 +816,7 @@ static hipError_t allow_stem_lds() {
     auto allow = [&](auto kernel, int bytes) {
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     };
-    constexpr int lp = (int)vts::PipeGeo<256, 128>::LDS_BYTES, lf = vts::FusedGeo::LDS_BYTES;
+    constexpr int lp = (int)vts::PipeGeo<256, 128>::LDS_BYTES, lf = vts::FusedGeo::LDS_BYTES_P;
     allow(&vts::stem_pipe_kernel<256, 128, 0, false>, lp);
     allow(&vts::stem_pipe_kernel<256, 128, 1, false>, lp);
     allow(&vts::stem_pipe_kernel<256, 128, 2, false>, lp);
@@ -1024,6 +1025,7 @@ void vt_destroy(vt_model* m) {
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
     m->stem_w3b.release();
+    m->stem_w4b.release();
     m->act_x.release(); m->act_z.release();
     DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->blocks3, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
@@ -1081,6 +1083,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
                 std::vector<float> as_f(img3.size() / 2);
                 std::memcpy(as_f.data(), img3.data(), img3.size() * 2);
                 if ((rc = upload(m->stem_w3b, as_f))) return rc;
+            }
+            if (i == 3) {   // layer 4 as three-piece bf16 images (stem_fused with VT_STEM_BF3): [out tile 3][pair 7][piece 3][64][8 bf16]
+                std::vector<uint16_t> img4((size_t)3 * 7 * 3 * 64 * 8, 0);
+                pack_conv_image3(w, STEM_CH[4], STEM_CH[3], img4.data());
+                std::vector<float> as_f(img4.size() / 2);
+                std::memcpy(as_f.data(), img4.data(), img4.size() * 2);
+                if ((rc = upload(m->stem_w4b, as_f))) return rc;
             }
         }
     }

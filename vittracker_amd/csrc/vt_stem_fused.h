@@ -60,6 +60,16 @@ struct FusedGeo {                       // TX = 128, TZ = 64
     // last interval (that ring dies an interval early and its group idles)
     static constexpr int W3L_OFF = 6 * NPIX3X + 6 * NPIX3Z, W3L_TILES = 2 * 4 * 3;
     static_assert(W3L_OFF >= RING + 0 && W3L_OFF + W3L_TILES * 64 <= 2 * RING, "layer-3 weight pieces must lie inside group B's ring");
+    // L3BF3 (round 4): layer 3 writes its output as PIECES (uint2 map[piece][plane][pixel]: 1.5 x the bytes) so that layer 4 runs as
+    // three-piece bf16 products too.  Search map: the rings' first 3 * 6 * NPIX3X uint2 = 2736 f4 (layer 3's weight pieces move up
+    // behind it, still inside group B's ring); template map: behind the offset tables, in LDS the fp32 form does not use.
+    static constexpr int M3XP_F4 = 3 * 6 * NPIX3X / 2, M3ZP_F4 = 3 * 6 * NPIX3Z / 2;                     // 2736, 864
+    static constexpr int W3P_OFF = M3XP_F4;
+    static_assert(W3P_OFF >= RING && W3P_OFF + W3L_TILES * 64 <= 2 * RING, "layer-3 weight pieces (piece-map form) must lie inside group B's ring");
+    static constexpr int M3ZP_OFF = LDS_F4;                                                              // f4 units from the LDS base
+    static constexpr int LDS_BYTES_P = (LDS_F4 + M3ZP_F4) * 16;                                          // 158,592
+    static_assert(LDS_BYTES_P <= 160 * 1024, "LDS");
+    static constexpr int W4P_UNITS = 3 * 7 * 3 * 64;                                                     // layer-4 weight pieces: [out tile 3][pair 7][piece 3][64 lanes] x 16 B
     static_assert((2 * R2X) * (TX / 4) == 512 && (2 * R2Z) * (TZ / 4) == 512, "one pixel pair per thread of a group");
 };
 
@@ -92,7 +102,8 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ pos_z, const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z, int skip_arg,
     unsigned long long* __restrict__ stamps,       // diagnostic (VT_DBG_STAMPS), null in production: [B][16][32]
     const float* __restrict__ w2k,                 // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
-    const float* __restrict__ w3b) {               // layer-3 weights as three-piece bf16 images [out tile 2][chunk pair 4][piece 3][64 lanes][8 bf16] (f32 build)
+    const float* __restrict__ w3b,                 // layer-3 weights as three-piece bf16 images [out tile 2][chunk pair 4][piece 3][64 lanes][8 bf16] (f32 build)
+    const float* __restrict__ w4b) {               // layer-4 weights, the same way: [out tile 3][chunk pair 7][piece 3][64 lanes][8 bf16]
     using G = FusedGeo;
     constexpr bool L3BF3 = L3B && !VT_IS_F16;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
@@ -104,6 +115,9 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     constexpr int M2Z_OFF = 3 * G::NPIX2X;
     f4* const m3x = lds;                                     // layer-3 maps reuse the rings (dead by then)
     f4* const m3z = lds + 6 * G::NPIX3X;
+    // L3BF3: the layer-3 maps as pieces, uint2 map[piece][plane][pixel] (FusedGeo): layer 4 runs on the bf16 pipe as well
+    vt3::u32x2* const m3xp = reinterpret_cast<vt3::u32x2*>(lds);
+    vt3::u32x2* const m3zp = reinterpret_cast<vt3::u32x2*>(lds + G::M3ZP_OFF);
     f4* const cw2 = lds + 2 * G::RING + 3 * G::NPIX2X + 3 * G::NPIX2Z;   // [5][64] layer-2 weight images
     const float* const cb2 = reinterpret_cast<const float*>(cw2 + 5 * 64);   // 16 floats
     const float* const cb3 = cb2 + 16;                                       // 32
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             if (grp == 1) {
                 for (int t = gw; t < G::W3L_TILES; t += 8)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3b + (size_t)t * 256 + lane * 4),
-                                                     (__attribute__((address_space(3))) void*)(lds + G::W3L_OFF + t * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(lds + G::W3P_OFF + t * 64), 16, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         } else {
@@ -410,15 +424,28 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const int item4 = z4 ? wave - 12 : wave;
     const int tile4 = z4 ? 0 : item4 / 3, ot4 = z4 ? item4 : item4 - 3 * tile4;
     f4 w4a[NCH4][1];
-    if (wave < 15) vtc::load_weights<1, NCH4, NCH4>(w4img + (size_t)ot4 * NCH4 * 256, 0, NCH4, lane, w4a);
+    if constexpr (!L3BF3) {
+        if (wave < 15) vtc::load_weights<1, NCH4, NCH4>(w4img + (size_t)ot4 * NCH4 * 256, 0, NCH4, lane, w4a);
+    }
     {
         // pads of the layer-3 maps (they alias the rings, which hold layer-1 data): row 0 and column -1
+        if constexpr (L3BF3) {
+            for (int i = threadIdx.x; i < 3 * 6 * (2 * 17 + 2 * 9); i += 1024) {        // every piece plane
+                const int pp = i / 52, e = i - pp * 52;                                 // pp = piece * 6 + plane
+                const vt3::u32x2 zero = {0u, 0u};
+                if (e < 17) m3xp[pp * G::NPIX3X + e] = zero;
+                else if (e < 34) m3xp[pp * G::NPIX3X + (e - 17) * 17 + 8] = zero;
+                else if (e < 43) m3zp[pp * G::NPIX3Z + (e - 34)] = zero;
+                else m3zp[pp * G::NPIX3Z + (e - 43) * 9 + 4] = zero;
+            }
+        } else {
         for (int i = threadIdx.x; i < 6 * (2 * 17 + 2 * 9); i += 1024) {
             const int plane = i / 52, e = i - plane * 52;
             if (e < 17) m3x[plane * G::NPIX3X + e] = splat4(0.f);                               // row 0
             else if (e < 34) m3x[plane * G::NPIX3X + (e - 17) * 17 + 8] = splat4(0.f);         // column -1
             else if (e < 43) m3z[plane * G::NPIX3Z + (e - 34)] = splat4(0.f);
             else m3z[plane * G::NPIX3Z + (e - 43) * 9 + 4] = splat4(0.f);
+        }
         }
         if constexpr (L3BF3) {
         // fp32 build: layer 3 as exact three-piece bf16 products.  The layer-2 maps stay fp32 (pre-split maps do not fit), so a B
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         if (!(skip & 4)) {
             using vt3::u32x2;
             using vt3::u32x4;
-            const u32x4* const W3L = reinterpret_cast<const u32x4*>(lds + G::W3L_OFF);
+            const u32x4* const W3L = reinterpret_cast<const u32x4*>(lds + G::W3P_OFF);
             constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
             auto unit3 = [&](const f4* map2, int base, const int* tab, f4 (&acc)[2]) {
                 int o3[G::OFF3];
@@ -467,7 +494,11 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                     if (16 * ot + 4 * q < 24) {
                         f4 r = acc[ot];
                         r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
-                        m3x[(4 * ot + q) * G::NPIX3X + (wave + 1) * P3 + ((px & 1) ? H3 + 1 + (px >> 1) : (px >> 1))] = r;
+                        u32x2 pcs[3];
+                        vt3::split3(r, pcs[0], pcs[1], pcs[2]);        // split ONCE where it is produced: layer 4 reads pieces
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            m3xp[(pc * 6 + 4 * ot + q) * G::NPIX3X + (wave + 1) * P3 + ((px & 1) ? H3 + 1 + (px >> 1) : (px >> 1))] = pcs[pc];
                     }
             }
             if (wave < 4 && do_z) {   // template: 4 pixel tiles of the 8 x 8 map
@@ -480,7 +511,11 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                     if (16 * ot + 4 * q < 24) {
                         f4 r = acc[ot];
                         r.x = hardswish(r.x); r.y = hardswish(r.y); r.z = hardswish(r.z); r.w = hardswish(r.w);
-                        m3z[(4 * ot + q) * G::NPIX3Z + (y + 1) * P3 + ((x & 1) ? H3 + 1 + (x >> 1) : (x >> 1))] = r;
+                        u32x2 pcs[3];
+                        vt3::split3(r, pcs[0], pcs[1], pcs[2]);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            m3zp[(pc * 6 + 4 * ot + q) * G::NPIX3Z + (y + 1) * P3 + ((x & 1) ? H3 + 1 + (x >> 1) : (x >> 1))] = pcs[pc];
                     }
             }
         }
@@ -535,6 +570,18 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
         }
         }
     }
+    // L3BF3: this wave's first two chunk pairs of layer-4 weight pieces are requested in FRONT of the barrier that ends layer 3 --
+    // their L2 round trip runs under the 2-3 k cycles most waves wait there (the fp32 form holds all of w4a from before layer 3)
+    vt3::u32x4 A4[4][3];
+    if constexpr (L3BF3) {
+        if (wave < 15 && !(skip & 8) && (z4 ? do_z : do_x)) {
+            const vt3::u32x4* const wg0 = reinterpret_cast<const vt3::u32x4*>(w4b) + (size_t)ot4 * (NCH4 / 2) * 3 * 64 + lane;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) A4[p][pc] = wg0[(p * 3 + pc) * 64];
+        }
+    }
     stamp();
     __syncthreads();
     stamp();
@@ -560,8 +607,49 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             }
         }
         auto off4 = [&](int c) { return o4[c]; };
+        if constexpr (L3BF3) {
+            // layer 4 as exact three-piece bf16 products: B operands are the pieces layer 3 wrote (two 8-byte reads per piece and chunk
+            // pair), A operands this output tile's weight pieces straight from L2, three pairs ahead; 7 pairs x 6 MFMAs on two
+            // accumulators (even / odd pairs) instead of 56 fp32 MFMAs.  Chunk 13 has two real quads and two pad quads (zero weights;
+            // their offsets clamp to a valid quad).
+            using vt3::u32x2;
+            using vt3::u32x4;
+            constexpr int NP4 = NCH4 / 2, TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+            const int ps = is_z ? 6 * G::NPIX3Z : 6 * G::NPIX3X;                    // piece stride (entries)
+            const u32x2* const mp = is_z ? m3zp : m3xp;
+            const u32x4* const wg = reinterpret_cast<const u32x4*>(w4b) + (size_t)ot * NP4 * 3 * 64 + lane;
+            auto load_a = [&](int p, u32x4 (&A)[3]) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) A[pc] = wg[(p * 3 + pc) * 64];
+            };
+            auto read_b = [&](int p, u32x4 (&Bv)[3]) {
+                const int o0 = base[0] + o4[2 * p], o1 = base[0] + o4[2 * p + 1];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const u32x2 lo = mp[pc * ps + o0], hi = mp[pc * ps + o1];
+                    Bv[pc] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            };
+            u32x4 (&A)[4][3] = A4;          // three pairs ahead: an L2 round trip is longer than two pairs' MFMAs
+            u32x4 Bv[2][3];
+            read_b(0, Bv[0]);
+            f4 accA = acc[0][0], accB = splat4(0.f);
+#pragma unroll
+            for (int p = 0; p < NP4; ++p) {
+                if (p + 3 < NP4) load_a(p + 3, A[(p + 3) & 3]);
+                if (p + 1 < NP4) read_b(p + 1, Bv[(p + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    if (p & 1) accB = vt3::mma(A[p & 3][TW[e]], Bv[p & 1][TX[e]], accB);
+                    else accA = vt3::mma(A[p & 3][TW[e]], Bv[p & 1][TX[e]], accA);
+                }
+            }
+            st4(tokens + ((size_t)b * L + (is_z ? 0 : len_z) + op) * 48 + 16 * ot + 4 * q, (accA + accB) + pe);
+        } else {
         vtc::mma_pass<1, 1, NCH4, NCH4>(map3, base, w4a, 0, off4, acc);
         st4(tokens + ((size_t)b * L + (is_z ? 0 : len_z) + op) * 48 + 16 * ot + 4 * q, acc[0][0] + pe);
+        }
     }
     stamp();
 }
