@@ -766,6 +766,20 @@ int crop_selftest() {
 }
 
 #ifdef VT_F16
+// a conv weight image in place: every 16-byte slot's float4 becomes h4 in its first 8 bytes (vt_conv.h load_weights)
+__global__ void opnd_inplace_kernel(float* __restrict__ img, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const opnd v = to_opnd(ld4(img + 4 * i));
+        *reinterpret_cast<opnd*>(img + 4 * i) = v;
+    }
+}
+int opnd_inplace(float* img, size_t nfloats) {
+    hipLaunchKernelGGL(opnd_inplace_kernel, dim3((unsigned)((nfloats / 4 + 255) / 256)), dim3(256), 0, nullptr, img, nfloats / 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return VT_OK;
+}
 // float4 -> h4 (the MFMA operand conversion of vt_common.h), n4 quads
 __global__ void f32_to_opnd_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1069,6 +1083,9 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             for (int o = 0; o < STEM_CH[i + 1]; ++o) bias[o] = (float)b[o];
             if ((rc = upload(m->stem_w[i], img))) return rc;
             if ((rc = upload(m->stem_b[i], bias))) return rc;
+#ifdef VT_F16
+            if (i >= 2 && (rc = opnd_inplace(m->stem_w[i].p, img.size()))) return rc;      // layers 3 / 4: stored operands (vt_conv.h); layer 2's image stays float4
+#endif
             if (i == 1) {   // [tap][ic / 4][16 oc][ic % 4]: element = w[oc][ic][tap], zero beyond 12 x 6
                 std::vector<float> k((size_t)9 * 2 * 16 * 4, 0.f);
                 for (int tap = 0; tap < 9; ++tap)
@@ -1198,6 +1215,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + vth::O_B5, p, nout * sizeof(float));
     }
     if ((rc = upload(m->head, hp))) return rc;
+#ifdef VT_F16
+    for (int t = 0; t < 3; ++t)      // the towers' conv images as stored operands, in place (biases and conv5 stay float)
+        for (int i = 0; i < 4; ++i) {
+            const int sizes[4] = {vth::O_B1 - vth::O_W1, vth::O_B2 - vth::O_W2, vth::O_B3 - vth::O_W3, vth::O_B4 - vth::O_W4};
+            if ((rc = opnd_inplace(m->head.p + (size_t)t * vth::TOWER_STRIDE + woff[i], (size_t)sizes[i]))) return rc;
+        }
+#endif
 #ifndef VT_F16
     if (m->F == 8) {     // the three-piece bf16 images of vt_head3.h (as floats: 16-byte units x 4)
         std::vector<float> as_f(hp3.size() / 2);

@@ -47,6 +47,7 @@ __device__ __forceinline__ void mfma4_shared_a(f4 a, const f4 (&b)[N], f4 (&acc)
 // fp32 number), the results bit-identical.  The fp32 build stores float4 and `opnd` is f4.
 typedef h4 opnd;
 __device__ __forceinline__ opnd to_opnd(f4 v) { return to_h4(v); }
+__device__ __forceinline__ f4 mfma4(h4 a, f4 b, f4 acc) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, to_h4(b), acc, 0, 0, 0); }
 template <int N>
 __device__ __forceinline__ void mfma4_shared_b(const h4 (&a)[N], f4 b, f4 (&acc)[N]) {
     const h4 hb = to_h4(b);

@@ -30,15 +30,29 @@ __device__ __forceinline__ void decode_quad(int Q, int& tap, int& icq) {
 // Request the weights of chunks [c0, c0 + n), n <= MAXC, of NOT consecutive output tiles.
 // NCH = chunks per output tile in the weight image (image stride).  Issue this as early as the
 // data flow allows: it does not depend on activations.
+// The image holds STORED operands (vt_common.h `opnd`): float4 in the fp32 build; in the f16 build vt_load_weights converts the
+// head's and the stem's layer-3 / layer-4 images in place -- a lane's four values as h4 in the first 8 bytes of its 16-byte slot,
+// so every float offset into an image stays valid -- and a load fetches 8 bytes and needs no conversion (round 4).
 template <int NOT, int MAXC, int NCH>
 __device__ __forceinline__ void load_weights(const float* __restrict__ wimg, int c0, int n, int lane,
-                                             f4 (&a)[MAXC][NOT]) {
+                                             opnd (&a)[MAXC][NOT]) {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k)
+        if (k < n)
+#pragma unroll
+            for (int ot = 0; ot < NOT; ++ot) a[k][ot] = *reinterpret_cast<const opnd*>(wimg + ((size_t)(ot * NCH + c0 + k) * 64 + lane) * 4);
+    __builtin_amdgcn_sched_barrier(0);      // keep the burst where it was written (the scheduler would sink it)
+}
+// the same from an image that stays float4 in both builds (the stem's layer 2, which other kernels also copy to LDS as it is)
+template <int NOT, int MAXC, int NCH>
+__device__ __forceinline__ void load_weights_f4(const float* __restrict__ wimg, int c0, int n, int lane,
+                                                f4 (&a)[MAXC][NOT]) {
 #pragma unroll
     for (int k = 0; k < MAXC; ++k)
         if (k < n)
 #pragma unroll
             for (int ot = 0; ot < NOT; ++ot) a[k][ot] = ld4(wimg + ((size_t)(ot * NCH + c0 + k) * 64 + lane) * 4);
-    __builtin_amdgcn_sched_barrier(0);      // keep the burst where it was written (the scheduler would sink it)
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // Accumulate chunks [c0, c0 + N) with preloaded weights for NPT pixel tiles x NOT output tiles.
@@ -48,8 +62,8 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wimg, int
 //   off(c)   per-lane map offset of this lane's quad of chunk c (tap + channel-quad part)
 // PIN: keep the next chunk's B reads ahead of this chunk's MFMAs (see below); costs registers, so opt-in.
 // General form: at(c, i) = per-lane map offset of this lane's quad of chunk c for pixel tile i.
-template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename AtFn>
-__device__ __forceinline__ void mma_pass_at(const f4* in_map, const f4 (&a)[MAXC][NOT], int c0, AtFn at, f4 (&acc)[NPT][NOT]) {
+template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename WT, typename AtFn>
+__device__ __forceinline__ void mma_pass_at(const f4* in_map, const WT (&a)[MAXC][NOT], int c0, AtFn at, f4 (&acc)[NPT][NOT]) {
     static_assert(N <= MAXC, "chunk count");
     f4 b[2][NPT];
 #pragma unroll
@@ -81,8 +95,8 @@ __device__ __forceinline__ void mma_pass_at(const f4* in_map, const f4 (&a)[MAXC
 }
 
 // The common case: offset = base[i] (tap (0,0) of pixel tile i) + off(c) (tap + channel-quad part of chunk c).
-template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename OffFn>
-__device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT], const f4 (&a)[MAXC][NOT], int c0,
+template <int NOT, int NPT, int MAXC, int N, bool PIN = false, typename WT, typename OffFn>
+__device__ __forceinline__ void mma_pass(const f4* in_map, const int (&base)[NPT], const WT (&a)[MAXC][NOT], int c0,
                                          OffFn off, f4 (&acc)[NPT][NOT]) {
     int oc = 0, ov = 0;      // off() of the last chunk asked for (at() is called for i = 0 .. NPT-1 of the same chunk in a row)
     bool have = false;
@@ -101,12 +115,12 @@ __device__ __forceinline__ void conv_all_chunks(const f4* in_map, const int (&ba
     constexpr int FULL = NCH / MAXC, REM = NCH % MAXC;
 #pragma unroll
     for (int p = 0; p < FULL; ++p) {
-        f4 a[MAXC][NOT];
+        opnd a[MAXC][NOT];
         load_weights<NOT, MAXC, NCH>(wimg, p * MAXC, MAXC, lane, a);
         mma_pass<NOT, NPT, MAXC, MAXC>(in_map, base, a, p * MAXC, off, acc);
     }
     if constexpr (REM > 0) {
-        f4 a[MAXC][NOT];
+        opnd a[MAXC][NOT];
         load_weights<NOT, MAXC, NCH>(wimg, FULL * MAXC, REM, lane, a);
         mma_pass<NOT, NPT, MAXC, REM>(in_map, base, a, FULL * MAXC, off, acc);
     }

@@ -98,7 +98,7 @@ struct HeadConv {
     static constexpr int MAXC = NCH < 9 ? NCH : 9;
     static constexpr int NPASS = (NCH + MAXC - 1) / MAXC;
     static_assert(NOT <= 2, "layers here have at most 2 output tiles");
-    f4 a[2][MAXC][1];
+    opnd a[2][MAXC][1];      // stored operands (vt_conv.h load_weights)
 
     __device__ __forceinline__ const float* wbase(const float* __restrict__ wimg, int wave) const {
         return wimg + (SPLIT_OT ? (size_t)(wave & 1) * NCH * 256 : 0);
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void head_conv1_kernel(const float* __restrict
     const int ot = wave & 1, lrow = wave >> 1;                       // output tile, row inside the strip
     const float* __restrict__ tw = hw + (size_t)t * TOWER_STRIDE;
     const float* __restrict__ wb = tw + O_W1 + (size_t)ot * NCH * 256;
-    f4 a[2][MAXC][1];
+    opnd a[2][MAXC][1];      // stored operands (vt_conv.h load_weights)
     vtc::load_weights<1, MAXC, NCH>(wb, 0, MAXC, lane, a[0]);
     for (int i = threadIdx.x; i < NQ * NPL; i += 512) strip[i] = splat4(0.f);
     __syncthreads();

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
         }
     }
     f4 w2a[5][1];                                // layer-2 weights: in flight across the barrier below
-    vtc::load_weights<1, 5, 5>(w2img, 0, 5, lane, w2a);
+    vtc::load_weights_f4<1, 5, 5>(w2img, 0, 5, lane, w2a);
     for (int i = threadIdx.x; i < 2 * NR1; i += 256)                     // column -1 of every row
         map1[(i / NR1) * npix1 + (i % NR1) * PITCH + HALF] = splat4(0.f);
     __syncthreads();
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a2_kernel(
         }
     }
     f4 w2a[5][1];                                // layer-2 weights: in flight across the barrier below
-    vtc::load_weights<1, 5, 5>(w2img, 0, 5, lane, w2a);
+    vtc::load_weights_f4<1, 5, 5>(w2img, 0, 5, lane, w2a);
     for (int i = threadIdx.x; i < 2 * (jx.NR1 + jz.NR1); i += 256) {     // column -1 of every row of both maps
         const bool zz = i >= 2 * jx.NR1;
         const int ii = zz ? i - 2 * jx.NR1 : i;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
     // Both weight bursts are requested before the data they multiply exists.
     constexpr int NCH3 = 7, NCH4 = 14;
     const int ot3 = wave & 1, th3 = wave >> 1;
-    f4 w3a[NCH3][1];
+    opnd w3a[NCH3][1];
     vtc::load_weights<1, NCH3, NCH3>(w3img + (size_t)ot3 * NCH3 * 256, 0, NCH3, lane, w3a);
 
     if (!(skip & 1))
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(CropB cx, CropB cz, const f
         }
     }
     const int c4_0 = (NCH4 * wave) >> 2, c4_n = ((NCH4 * (wave + 1)) >> 2) - c4_0;     // 3, 4, 3, 4 chunks
-    f4 w4a[4][3];
+    opnd w4a[4][3];
     vtc::load_weights<3, 4, NCH4>(w4img, c4_0, c4_n, lane, w4a);
     __syncthreads();
 

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     constexpr int NCH4 = 14;
     constexpr int NCH3 = 7;
     const int ot3 = wave & 1;
-    f4 w3a[NCH3][1];
+    opnd w3a[NCH3][1];
     // L3BF3: layer 3 runs as three-piece bf16 products (vt_bf3.h): every wave needs the WHOLE image, so it goes through LDS.  Group B's
     // eight waves stage it (three LDS-DMA pieces each) in the interval in which they have nothing else to do.
     auto load_w3 = [&]() {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const bool z4 = wave >= 12;
     const int item4 = z4 ? wave - 12 : wave;
     const int tile4 = z4 ? 0 : item4 / 3, ot4 = z4 ? item4 : item4 - 3 * tile4;
-    f4 w4a[NCH4][1];
+    opnd w4a[NCH4][1];
     if constexpr (!L3BF3) {
         if (wave < 15) vtc::load_weights<1, NCH4, NCH4>(w4img + (size_t)ot4 * NCH4 * 256, 0, NCH4, lane, w4a);
     }
