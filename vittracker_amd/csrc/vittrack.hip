@@ -19,6 +19,9 @@
 #include "vt_blocks.h"
 #include "vt_blocks_tile.h"
 #include "vt_head.h"
+#ifndef VT_SEQ3_MAXP
+#define VT_SEQ3_MAXP 2      // head_seq3: conv1 weight pairs per register pass
+#endif
 #include "vt_head3.h"
 #include "vt_stem.h"
 #include "vt_stem_fused.h"
@@ -622,6 +625,15 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
                                score, size, offset, m->skip_head);
     } else if (m->F == 16 && (m->head_fused < 0 ? Bf > 176 : m->head_fused != 0)) {
         // one workgroup per frame: the three towers in turn on one staged input map, decode from LDS (no decode launch)
+#ifndef VT_F16
+        if (m->head_bf3 && !m->skip_head) {      // conv1 as three-piece bf16 products (vt_head3.h head_seq3)
+            hipLaunchKernelGGL((vth3::head_seq3_kernel<8, VT_SEQ3_MAXP>), dim3(B), dim3(512), vth3::SEQ3_LDS_BYTES, st, feat, m->head.p,
+                               reinterpret_cast<const vth3::u32x4*>(m->head3.p), m->window.p, score, size, offset, pred, hann, conf,
+                               tail ? *tail : TrackTail{}, tail ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            return VT_OK;       // (tail: on the kernel's decoding lane)
+        }
+#endif
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(B), dim3(512), vth::SeqHeadGeo<16>::LDS_BYTES, st, feat, m->head.p, m->window.p, score,
                                size, offset, pred, hann, conf, m->skip_head, tail ? *tail : TrackTail{}, tail ? 1 : 0);
@@ -1005,6 +1017,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_towers3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     vth3::TOWERS3_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, vth3::SEQ3_LDS_BYTES);
 #endif
         if (e == hipSuccess)
             e = allow_stem_lds();
@@ -1186,7 +1201,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
 #ifndef VT_F16
-    std::vector<uint16_t> hp3(m->F == 8 ? (size_t)3 * vth3::TOWER3_STRIDE * 8 : 0, 0);
+    std::vector<uint16_t> hp3((size_t)3 * vth3::TOWER3_STRIDE * 8, 0);
 #endif
     const char* towers[3] = {"ctr", "offset", "size"};
     const int chans[5] = {48, 32, 16, 8, 4};
@@ -1200,7 +1215,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, chans[i + 1], chans[i], w, b))) return rc;
             pack_conv_image(w, chans[i + 1], chans[i], dst + woff[i]);
 #ifndef VT_F16
-            if (m->F == 8) {
+            {
                 const int woff3[4] = {vth3::O3_W1, vth3::O3_W2, vth3::O3_W3, vth3::O3_W4};
                 pack_conv_image3(w, chans[i + 1], chans[i], hp3.data() + ((size_t)t * vth3::TOWER3_STRIDE + woff3[i]) * 8);
             }
@@ -1223,7 +1238,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         }
 #endif
 #ifndef VT_F16
-    if (m->F == 8) {     // the three-piece bf16 images of vt_head3.h (as floats: 16-byte units x 4)
+    {     // the three-piece bf16 images of vt_head3.h (as floats: 16-byte units x 4); F = 16 reads conv1's only
         std::vector<float> as_f(hp3.size() / 2);
         std::memcpy(as_f.data(), hp3.data(), hp3.size() * 2);
         if ((rc = upload(m->head3, as_f))) return rc;

@@ -459,6 +459,50 @@ __global__ __launch_bounds__(512) void head_conv1_kernel(const float* __restrict
     dst[G::interior(ROWS * sg + lrow, px)] = v;
 }
 
+// cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105); one wave.
+// outs: the score plane [F * F] (LDS); sz, of: the size / offset planes [2][F * F], gathered at the two winning pixels only (LDS
+// copies, or the global maps this workgroup wrote before its last barrier)
+template <int F>
+__device__ __forceinline__ void seq_decode(const float* outs, const float* sz, const float* of, const float* __restrict__ window,
+                                           int b, int lane, float* __restrict__ pred, float* __restrict__ hann,
+                                           float* __restrict__ conf, const TrackTail& tail, int has_tail) {
+    constexpr int n = F * F;
+    float v0 = -3.0e38f, v1 = -3.0e38f;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float sc = outs[i];
+        argmax_merge(v0, i0, sc, i);
+        if (window != nullptr) argmax_merge(v1, i1, window[i] * sc, i);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
+        argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
+    }
+    if (i0 >= n) i0 = 0;      // a map of NaNs never beats the initial value: keep the gathers in bounds (as decode_kernel)
+    if (i1 >= n) i1 = 0;
+    if (lane == 0) {
+        const float fF = (float)F;
+        if (pred != nullptr) {
+            pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
+            pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
+            pred[b * 4 + 2] = sz[i0];
+            pred[b * 4 + 3] = sz[n + i0];
+        }
+        if (window != nullptr && (hann != nullptr || has_tail)) {
+            const float hb[4] = {((float)(i1 % F) + of[i1]) / fF, ((float)(i1 / F) + of[n + i1]) / fF, sz[i1], sz[n + i1]};
+            if (hann != nullptr) {
+                hann[b * 4 + 0] = hb[0];
+                hann[b * 4 + 1] = hb[1];
+                hann[b * 4 + 2] = hb[2];
+                hann[b * 4 + 3] = hb[3];
+            }
+            if (has_tail) update_state_one(b, hb, v0, tail);
+        }
+        if (conf != nullptr) conf[b] = v0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ head_seq
 // F = 16 (129 KB of maps: one workgroup per CU whatever the form): one workgroup per FRAME runs the three towers one after
 // the other on ONE staged input map and decodes from LDS -- instead of three workgroups per frame (head_towers) that each clear
@@ -537,45 +581,7 @@ __global__ __launch_bounds__(NW * 64) void head_seq_kernel(const float* __restri
         // the barrier that follows conv1: the 1x1 reads of m2 above need no barrier of their own
     }
     __syncthreads();
-    // cal_bbox on the raw score and on window * score (head.py:142-160; lib/test/tracker/vit_dist.py:103-105)
-    if (wave == 0) {
-        float v0 = -3.0e38f, v1 = -3.0e38f;
-        int i0 = 0x7fffffff, i1 = 0x7fffffff;
-        for (int i = lane; i < n; i += 64) {
-            const float sc = outs[i];
-            argmax_merge(v0, i0, sc, i);
-            if (window != nullptr) argmax_merge(v1, i1, window[i] * sc, i);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            argmax_merge(v0, i0, __shfl_xor(v0, off, 64), __shfl_xor(i0, off, 64));
-            argmax_merge(v1, i1, __shfl_xor(v1, off, 64), __shfl_xor(i1, off, 64));
-        }
-        if (i0 >= n) i0 = 0;      // a map of NaNs never beats the initial value: keep the gathers in bounds (as decode_kernel)
-        if (i1 >= n) i1 = 0;
-        if (lane == 0) {
-            const float fF = (float)F;
-            const float* sz = outs + n;
-            const float* of = outs + 3 * n;
-            if (pred != nullptr) {
-                pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
-                pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
-                pred[b * 4 + 2] = sz[i0];
-                pred[b * 4 + 3] = sz[n + i0];
-            }
-            if (window != nullptr && (hann != nullptr || has_tail)) {
-                const float hb[4] = {((float)(i1 % F) + of[i1]) / fF, ((float)(i1 / F) + of[n + i1]) / fF, sz[i1], sz[n + i1]};
-                if (hann != nullptr) {
-                    hann[b * 4 + 0] = hb[0];
-                    hann[b * 4 + 1] = hb[1];
-                    hann[b * 4 + 2] = hb[2];
-                    hann[b * 4 + 3] = hb[3];
-                }
-                if (has_tail) update_state_one(b, hb, v0, tail);
-            }
-            if (conf != nullptr) conf[b] = v0;
-        }
-    }
+    if (wave == 0) seq_decode<F>(outs, outs + n, outs + 3 * n, window, b, lane, pred, hann, conf, tail, has_tail);
 }
 
 }  // namespace vth

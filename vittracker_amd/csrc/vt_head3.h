@@ -419,5 +419,178 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------ head_seq3 (F = 16)
+// The sequential head of vt_head.h (one workgroup per frame runs the three towers in turn on ONE staged input map) with conv1 --
+// 70 % of a tower's MACs -- as three-piece bf16 products.  Only the INPUT map is held as pieces (tokens are split once, at staging,
+// and read by three towers): with conv1's output as pieces too the maps would need 190 KB.  conv1 writes fp32, conv2-4 are
+// vt_head.h's fp32-MFMA layers unchanged.  LDS: input pieces 94.5 KB + m1 42 KB + m2 21 KB + the score plane 1 KB = 158.5 KB; the
+// decode gathers size / offset at its two winning pixels from the global maps the workgroup has just written.
+using G16 = vth::Geo<16>;
+constexpr int SEQ3_IN_E = 3 * (C / 4) * G16::NPIX;                                         // uint2 entries
+constexpr int SEQ3_LDS_BYTES = SEQ3_IN_E * 8 + (W1 / 4 + 4) * G16::NPIX * 16 + 256 * 4;
+static_assert(SEQ3_LDS_BYTES <= 160 * 1024, "LDS");
+// a quarter-wave reads 16 consecutive 8-byte entries (128 B); the two quarter-waves a ds_read_b64 pass serves together read planes
+// icq and icq + 1: NPIX * 8 = 128 (mod 256) puts them in complementary bank halves
+static_assert((G16::NPIX * 8) % 256 == 128, "piece planes: conflict-free ds_read_b64");
+
+// conv1 (48 -> 32, 3 x 3) + bias + ReLU from the piece-planar input map to the fp32 map m1.  Work split as vth::HeadConv: wave ->
+// (output tile wave & 1, pixel tiles (wave >> 1) + NW / 2 * i).  Weights: the [ot][pair][piece][lane] image of head_fused3, in
+// register passes of MAXP chunk pairs, double-buffered.
+template <int NW, int MAXP>
+struct SeqConv1 {
+    static constexpr int NQ = C / 4, NCH = nchunks(C), NCP = npairs(C), TSTEP = NW / 2, NPT = G16::NT / TSTEP;
+    static constexpr int NPASS = (NCP + MAXP - 1) / MAXP, LASTN = NCP - (NPASS - 1) * MAXP;
+    static constexpr int PS_IN = NQ * G16::NPIX;
+    static_assert(NQ % 4 == 0 && G16::NT % TSTEP == 0, "a chunk never straddles two taps; pixel tiles divide over the waves");
+    u32x4 a[2][MAXP][3];
+
+    __device__ __forceinline__ void load_pass(const u32x4* __restrict__ wb, int p0, int n, int lane, u32x4 (&dst)[MAXP][3]) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (k < n)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) dst[k][pc] = wb[((size_t)(p0 + k) * 3 + pc) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wimg, int wave, int lane) {
+        load_pass(wimg + (size_t)(wave & 1) * NCP * 192, 0, MAXP, lane, a[0]);
+    }
+    __device__ __forceinline__ void run(const u32x2* in_map, f4* out_map, const u32x4* __restrict__ wimg,
+                                        const float* __restrict__ bias, int wave, int lane) {
+        const int q = lane >> 4, ot = wave & 1, tfirst = wave >> 1;
+        const u32x4* __restrict__ wb = wimg + (size_t)ot * NCP * 192;
+        f4 acc[NPT];
+        const f4 bv = ld4(bias + 16 * ot + 4 * q);
+        int base[NPT];      // tap (0,0) of this lane's pixel of tile i in plane q: one row up, one column left in the zero-bordered grid
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) { acc[i] = bv; base[i] = q * G16::NPIX + (tfirst + TSTEP * i) * G16::P + (lane & 15); }
+        // entry offset (compile-time part) of chunk c: its tap and its first channel quad
+        auto off = [&](int c) {
+            const int cc = c < NCH ? c : NCH - 1, tap = (4 * cc) / NQ, icq0 = 4 * cc - tap * NQ, dy = tap / 3, dx = tap - 3 * dy;
+            return icq0 * G16::NPIX + dy * G16::P + dx;
+        };
+        // one opaque LDS base per (pixel tile, piece): every chunk offset (< 30 KB) then sits in the instruction's offset field
+        lds_cptr<u32x2> pb[NPT][3];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) pb[i][pc] = lds_lane_base<u32x2>(in_map + pc * PS_IN, base[i] * 8);
+        auto read_b = [&](int cp, u32x4 (&b)[NPT][3]) {
+            const int o0 = off(2 * cp), o1 = off(2 * cp + 1);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const u32x2 lo = pb[i][pc][o0], hi = pb[i][pc][o1];
+                    b[i][pc] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+        };
+        u32x4 b[2][NPT][3];
+        read_b(0, b[0]);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int n = p + 1 < NPASS ? MAXP : LASTN;
+            if (p + 1 < NPASS) load_pass(wb, (p + 1) * MAXP, p + 2 < NPASS ? MAXP : LASTN, lane, a[(p + 1) & 1]);
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                if (k >= n) break;
+                const int cp = p * MAXP + k;
+                if (cp + 1 < NCP) {
+                    read_b(cp + 1, b[(cp + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);        // keep the next pair's reads ahead of this pair's MFMAs
+                }
+                const u32x4 (&w)[3] = a[p & 1][k];
+                // term by term over the pixel tiles: consecutive MFMAs never share an accumulator
+                auto mm = [&](int wp, int xp) {
+#pragma unroll
+                    for (int i = 0; i < NPT; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[wp]), __builtin_bit_cast(bf16x8, b[cp & 1][i][xp]), acc[i], 0, 0, 0);
+                };
+                mm(2, 0); mm(0, 2); mm(1, 1); mm(1, 0); mm(0, 1); mm(0, 0);      // smallest terms first
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            f4 v = acc[i];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            out_map[(4 * ot) * G16::NPIX + base[i] + G16::P + 1] = v;      // base carries q * NPIX
+        }
+    }
+};
+
+// grid B, NW * 64 threads.  Arguments as vth::head_seq_kernel + hw3 (the piece images; only conv1's are read).
+template <int NW, int MAXP>
+__global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
+                                                        const u32x4* __restrict__ hw3, const float* __restrict__ window,
+                                                        float* __restrict__ score, float* __restrict__ size,
+                                                        float* __restrict__ offset, float* __restrict__ pred,
+                                                        float* __restrict__ hann, float* __restrict__ conf, TrackTail tail,
+                                                        int has_tail) {
+    constexpr int F = 16, n = F * F;
+    static_assert(NW * 64 >= n, "one thread per pixel in the 1 x 1 stage");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    f4* m1 = reinterpret_cast<f4*>(sm);                          // 8 quads (the fp32 maps first: their offsets fit the LDS
+    f4* m2 = m1 + (W1 / 4) * G16::NPIX;                          // 4 quads  instructions' 16-bit offset field)
+    float* sc = reinterpret_cast<float*>(m2 + 4 * G16::NPIX);    // the score plane, for the decode's argmax
+    u32x2* in_map = reinterpret_cast<u32x2*>(sc + 256);          // 3 pieces x 12 quads
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    SeqConv1<NW, MAXP> c1;
+    vth::HeadConv<W1, 16, F, NW> c2;
+    vth::HeadConv<16, 8, F, NW> c3;
+    vth::HeadConv<8, 4, F, NW> c4;
+    c1.prefetch(hw3 + O3_W1, wave, lane);      // first weight pass flies during the map set-up
+    for (int i = threadIdx.x; i < SEQ3_LDS_BYTES / 16; i += NW * 64) reinterpret_cast<u32x4*>(sm)[i] = u32x4{0, 0, 0, 0};
+    __syncthreads();
+    // (B,HW,C) tokens -> piece planes, once for the three towers   (vit_dist.py:126-129)
+    for (int i = threadIdx.x; i < n * (C / 4); i += NW * 64) {
+        const int icq = i / n, pix = i % n;
+        u32x2 h, m, l;
+        split3(ld4(feat + ((size_t)b * n + pix) * C + 4 * icq), h, m, l);
+        const int e = icq * G16::NPIX + G16::interior(pix / F, pix % F);
+        in_map[e] = h; in_map[(C / 4) * G16::NPIX + e] = m; in_map[2 * (C / 4) * G16::NPIX + e] = l;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {              // tower 0 = ctr, 1 = offset, 2 = size
+        const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
+        const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
+        c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
+        c2.prefetch(tw + vth::O_W2, wave, lane);    // (not before conv1: its working set is 200 registers)
+        c3.prefetch(tw + vth::O_W3, wave, lane);    // the later layers' first bursts are requested a layer early
+        __syncthreads();
+        c2.run(m1, m2, tw + vth::O_W2, tw + vth::O_B2, wave, lane);
+        c4.prefetch(tw + vth::O_W4, wave, lane);
+        __syncthreads();
+        c3.run(m2, m1, tw + vth::O_W3, tw + vth::O_B3, wave, lane);
+        __syncthreads();
+        c4.run(m1, m2, tw + vth::O_W4, tw + vth::O_B4, wave, lane);
+        if (t < 2) c1.prefetch(tw3 + TOWER3_STRIDE + O3_W1, wave, lane);   // the next tower's first pass
+        __syncthreads();
+        // 1x1 conv + activation (head.py:187,194,200-201) -> global maps (+ the score plane in LDS)
+        if (threadIdx.x < n) {
+            const int pix = threadIdx.x;
+            const f4 v = m2[G16::interior(pix / F, pix % F)];
+            const int nout = (t == 0) ? 1 : 2;
+            for (int o = 0; o < nout; ++o) {
+                const f4 w5 = ld4(tw + vth::O_W5 + 4 * o);
+                float y = tw[vth::O_B5 + o];
+                y = fmaf(v.x, w5.x, y); y = fmaf(v.y, w5.y, y); y = fmaf(v.z, w5.z, y); y = fmaf(v.w, w5.w, y);
+                if (t == 0) { y = sigmoid_clamped(y); score[(size_t)b * n + pix] = y; sc[pix] = y; }
+                else if (t == 2) size[((size_t)b * 2 + o) * n + pix] = sigmoid_clamped(y);
+                else offset[((size_t)b * 2 + o) * n + pix] = y;
+            }
+        }
+        // the next tower's conv1 writes m1 (last read by c4, before the barrier above) and its conv2 writes m2 only after
+        // the barrier that follows conv1: the 1x1 reads of m2 above need no barrier of their own
+    }
+    // size / offset of this frame were written by this workgroup's own threads: the barrier (workgroup-scope release / acquire)
+    // makes them visible to the decoding wave
+    __syncthreads();
+    if (wave == 0) vth::seq_decode<F>(sc, size + (size_t)b * 2 * n, offset + (size_t)b * 2 * n, window, b, lane, pred, hann, conf, tail, has_tail);
+}
+
 }  // namespace vth3
 #endif  // !VT_F16
