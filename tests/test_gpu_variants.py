@@ -49,8 +49,9 @@ VARIANTS = {
     "two_kernel_stem_joint_bands": {"VT_STEM_FUSED": "0", "VT_STEM_FUSE": "1"},
     "g256_stem_a_instead_of_stem_pipe": {"VT_STEM_PIPE": "0"},
     "per_tower_head": {"VT_HEAD_FUSED": "0", "VT_HEAD_SPLIT": "0"},
-    # the G128 head's towers on the bf16 matrix pipe with exact three-piece operands (vt_head3.h; the default), both kernel forms,
-    # and the fp32-MFMA towers they replaced (VT_HEAD_BF3=0; F = 16 always runs those)
+    # the head's towers on the bf16 matrix pipe with exact three-piece operands (vt_head3.h; the default: all four layers at G128,
+    # conv1 of the one-workgroup-per-frame form at G256 = head_seq3), both kernel forms, and the fp32-MFMA towers they replaced
+    # (VT_HEAD_BF3=0)
     "head_bf16x3_small_batch_form": {"VT_HEAD_BF3": "1"},
     "head_bf16x3_fused_form": {"VT_HEAD_BF3": "1", "VT_HEAD_FUSED": "1"},
     "head_fp32_mfma_small_batch_form": {"VT_HEAD_BF3": "0"},

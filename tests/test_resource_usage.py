@@ -20,7 +20,7 @@ DEFAULT_VIT48 = [
     (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), true>", 256),       # 512 threads
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true>", 256),
     (r"vth3::head_fused3_kernel", 168),                              # 768 threads
-    (r"vth::head_seq_kernel<16, 8, false>", 256),
+    (r"vth3::head_seq3_kernel<8, 2, false>", 256),
     # small batches / the plugin's one-sequence step
     (r"vts::stem_a_kernel", 256), (r"vts::stem_b_kernel<false>", 256),
     (r"vtb::tile_qkv_kernel<(5|20)>", 512), (r"vtb::tile_attn_mlp_kernel<(5|20)>", 256),
@@ -29,6 +29,7 @@ DEFAULT_VIT48 = [
     # fp32-MFMA forms selected by VT_*_BF3=0 (bench.py's all-fp32 comparison)
     (r"vts::stem_fused_kernel<[012], false, false>", 128), (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), false>", 256),
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), false>", 256), (r"vth::head_fused_kernel<8, false>", 168),
+    (r"vth::head_seq_kernel<16, 8, false>", 256),
 ]
 # vts::stem_a2_kernel reports ScratchSize 36 with VGPRs Spill 0 and not one scratch instruction: SGPRs spilled to VGPR lanes reserve a
 # frame that is never touched.  It must stay free of VGPR spills.

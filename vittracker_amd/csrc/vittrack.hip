@@ -627,9 +627,13 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         // one workgroup per frame: the three towers in turn on one staged input map, decode from LDS (no decode launch)
 #ifndef VT_F16
         if (m->head_bf3 && !m->skip_head) {      // conv1 as three-piece bf16 products (vt_head3.h head_seq3)
-            hipLaunchKernelGGL((vth3::head_seq3_kernel<8, VT_SEQ3_MAXP>), dim3(B), dim3(512), vth3::SEQ3_LDS_BYTES, st, feat, m->head.p,
-                               reinterpret_cast<const vth3::u32x4*>(m->head3.p), m->window.p, score, size, offset, pred, hann, conf,
-                               tail ? *tail : TrackTail{}, tail ? 1 : 0);
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(B), dim3(512), vth3::SEQ3_LDS_BYTES, st, feat, m->head.p,
+                                   reinterpret_cast<const vth3::u32x4*>(m->head3.p), m->window.p, score, size, offset, pred, hann, conf,
+                                   tail ? *tail : TrackTail{}, tail ? 1 : 0, m->dbg_stamps);
+            };
+            if (m->dbg_stamps) go(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP, true>);
+            else go(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP, false>);
             HIP_TRY(hipGetLastError());
             return VT_OK;       // (tail: on the kernel's decoding lane)
         }
@@ -1018,7 +1022,10 @@ int vt_create(const vt_config* cfg, vt_model** out) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_towers3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     vth3::TOWERS3_LDS_BYTES);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, vth3::SEQ3_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vth3::head_seq3_kernel<8, VT_SEQ3_MAXP, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, vth3::SEQ3_LDS_BYTES);
 #endif
         if (e == hipSuccess)

@@ -24,7 +24,7 @@
 
 #ifndef VT_F16
 #ifndef VT_H3_SKIP
-#define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs, 4 = no weight loads in conv1
+#define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs (head_seq3: no conv2), 4 = no weight loads in conv1, 8 = head_seq3: no conv3 / conv4
 #endif
 namespace vth3 {
 
@@ -519,13 +519,14 @@ struct SeqConv1 {
 };
 
 // grid B, NW * 64 threads.  Arguments as vth::head_seq_kernel + hw3 (the piece images; only conv1's are read).
-template <int NW, int MAXP>
+// DIAG: s_memtime stamps per wave and phase (VT_DBG_STAMPS, tools/head_stamps.py); compiled out of the production instantiation.
+template <int NW, int MAXP, bool DIAG = false>
 __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restrict__ feat, const float* __restrict__ hw,
                                                         const u32x4* __restrict__ hw3, const float* __restrict__ window,
                                                         float* __restrict__ score, float* __restrict__ size,
                                                         float* __restrict__ offset, float* __restrict__ pred,
                                                         float* __restrict__ hann, float* __restrict__ conf, TrackTail tail,
-                                                        int has_tail) {
+                                                        int has_tail, unsigned long long* __restrict__ stamps) {
     constexpr int F = 16, n = F * F;
     static_assert(NW * 64 >= n, "one thread per pixel in the 1 x 1 stage");
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -538,17 +539,36 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     SeqConv1<NW, MAXP> c1;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if constexpr (DIAG) {
+            if (stamps != nullptr && lane == 0) stamps[((size_t)b * NW + wave) * 64 + nstamp] = __builtin_amdgcn_s_memtime();
+            ++nstamp;
+        }
+    };
+    stamp();
     vth::HeadConv<W1, 16, F, NW> c2;
     vth::HeadConv<16, 8, F, NW> c3;
     vth::HeadConv<8, 4, F, NW> c4;
     c1.prefetch(hw3 + O3_W1, wave, lane);      // first weight pass flies during the map set-up
+    // (B,HW,C) tokens -> piece planes, once for the three towers (vit_dist.py:126-129): requested before the LDS is cleared so that
+    // their L2 / HBM round trip runs under the clear and its barrier (stamps: 7.4 k cycles when requested after it, item by item)
+    constexpr int NST = n * (C / 4) / (NW * 64);
+    static_assert(n * (C / 4) % (NW * 64) == 0, "staged items divide over the threads");
+    f4 tok[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = threadIdx.x + k * NW * 64, icq = i / n, pix = i % n;
+        tok[k] = ld4(feat + ((size_t)b * n + pix) * C + 4 * icq);
+    }
     for (int i = threadIdx.x; i < SEQ3_LDS_BYTES / 16; i += NW * 64) reinterpret_cast<u32x4*>(sm)[i] = u32x4{0, 0, 0, 0};
     __syncthreads();
-    // (B,HW,C) tokens -> piece planes, once for the three towers   (vit_dist.py:126-129)
-    for (int i = threadIdx.x; i < n * (C / 4); i += NW * 64) {
-        const int icq = i / n, pix = i % n;
+    stamp();
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = threadIdx.x + k * NW * 64, icq = i / n, pix = i % n;
         u32x2 h, m, l;
-        split3(ld4(feat + ((size_t)b * n + pix) * C + 4 * icq), h, m, l);
+        split3(tok[k], h, m, l);
         const int e = icq * G16::NPIX + G16::interior(pix / F, pix % F);
         in_map[e] = h; in_map[(C / 4) * G16::NPIX + e] = m; in_map[2 * (C / 4) * G16::NPIX + e] = l;
     }
@@ -557,21 +577,31 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     for (int t = 0; t < 3; ++t) {              // tower 0 = ctr, 1 = offset, 2 = size
         const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
         const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
-        c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
+        stamp();
+        if (!(VT_H3_SKIP & 1)) c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
         c2.prefetch(tw + vth::O_W2, wave, lane);    // (not before conv1: its working set is 200 registers)
         c3.prefetch(tw + vth::O_W3, wave, lane);    // the later layers' first bursts are requested a layer early
+        stamp();
         __syncthreads();
-        c2.run(m1, m2, tw + vth::O_W2, tw + vth::O_B2, wave, lane);
+        stamp();
+        if (!(VT_H3_SKIP & 2)) c2.run(m1, m2, tw + vth::O_W2, tw + vth::O_B2, wave, lane);
         c4.prefetch(tw + vth::O_W4, wave, lane);
+        stamp();
         __syncthreads();
-        c3.run(m2, m1, tw + vth::O_W3, tw + vth::O_B3, wave, lane);
+        stamp();
+        if (!(VT_H3_SKIP & 8)) c3.run(m2, m1, tw + vth::O_W3, tw + vth::O_B3, wave, lane);
+        stamp();
         __syncthreads();
-        c4.run(m1, m2, tw + vth::O_W4, tw + vth::O_B4, wave, lane);
+        stamp();
+        if (!(VT_H3_SKIP & 8)) c4.run(m1, m2, tw + vth::O_W4, tw + vth::O_B4, wave, lane);
         if (t < 2) c1.prefetch(tw3 + TOWER3_STRIDE + O3_W1, wave, lane);   // the next tower's first pass
+        stamp();
         __syncthreads();
+        stamp();
         // 1x1 conv + activation (head.py:187,194,200-201) -> global maps (+ the score plane in LDS)
         if (threadIdx.x < n) {
-            const int pix = threadIdx.x;
+            int pix = threadIdx.x;
+            asm volatile("" : "+v"(pix));      // addresses are rebuilt here per tower: hoisted out of the tower loop they were spilled
             const f4 v = m2[G16::interior(pix / F, pix % F)];
             const int nout = (t == 0) ? 1 : 2;
             for (int o = 0; o < nout; ++o) {
@@ -588,8 +618,15 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     }
     // size / offset of this frame were written by this workgroup's own threads: the barrier (workgroup-scope release / acquire)
     // makes them visible to the decoding wave
+    stamp();
     __syncthreads();
-    if (wave == 0) vth::seq_decode<F>(sc, size + (size_t)b * 2 * n, offset + (size_t)b * 2 * n, window, b, lane, pred, hann, conf, tail, has_tail);
+    stamp();
+    if (wave == 0) {
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));          // (the decode's lane and addresses are built here, not held across the tower loop)
+        const int dl = tx & 63;
+        vth::seq_decode<F>(sc, size + (size_t)b * 2 * n, offset + (size_t)b * 2 * n, window, b, dl, pred, hann, conf, tail, has_tail);
+    }
 }
 
 }  // namespace vth3
