@@ -23,7 +23,8 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ src, float* _
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
                 if (KIND == 0) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, s[j & 1]), __builtin_bit_cast(b8, s[2 + ((j >> 1) & 1)]), acc[j], 0, 0, 0);
-                else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s[j & 1][j & 3], s[2 + ((j >> 1) & 1)][j & 3], acc[j], 0, 0, 0);
+                else if (KIND == 1) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s[j & 1][j & 3], s[2 + ((j >> 1) & 1)][j & 3], acc[j], 0, 0, 0);
+                else acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(s[j & 1][j & 3], s[2 + ((j >> 1) & 1)][j & 3], acc[j], 0, 0, 0);
             }
         }
     }
@@ -60,5 +61,7 @@ int main() {
     run<0, 8, false>("v_mfma_f32_16x16x32_bf16"); run<0, 8, true>("v_mfma_f32_16x16x32_bf16");
     run<1, 4, false>("v_mfma_f32_16x16x4_f32"); run<1, 4, true>("v_mfma_f32_16x16x4_f32");
     run<1, 8, false>("v_mfma_f32_16x16x4_f32"); run<1, 8, true>("v_mfma_f32_16x16x4_f32");
+    run<2, 4, false>("v_mfma_f32_4x4x1_16b_f32"); run<2, 4, true>("v_mfma_f32_4x4x1_16b_f32");
+    run<2, 8, false>("v_mfma_f32_4x4x1_16b_f32"); run<2, 8, true>("v_mfma_f32_4x4x1_16b_f32");
     return 0;
 }

@@ -12,6 +12,28 @@ __global__ void lanemap(float* out) {
     d = __builtin_amdgcn_mfma_f32_4x4x1f32(1.f + i + 10.f * b, 1.f + i + 100.f * b, d, 0, 0, 0);
     for (int v = 0; v < 4; ++v) out[lane * 4 + v] = d[v];
 }
+// A-operand broadcast: cbsz = 4, abid = AB -> every block multiplies by block AB's A values (so one register holds the A rows of
+// sixteen different k, selected per instruction)
+template <int AB>
+__global__ void lanemap_bcast(float* out) {
+    const int lane = threadIdx.x, b = lane >> 2, i = lane & 3;
+    f4 d = {};
+    d = __builtin_amdgcn_mfma_f32_4x4x1f32(1.f + i + 10.f * b, 1.f + i + 100.f * b, d, 4, AB, 0);
+    for (int v = 0; v < 4; ++v) out[lane * 4 + v] = d[v];
+}
+template <int AB>
+int check_bcast(float* d) {
+    hipLaunchKernelGGL(lanemap_bcast<AB>, dim3(1), dim3(64), 0, 0, d);
+    float h[256]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+            const int b = lane >> 2, j = lane & 3;
+            if (h[lane * 4 + r] != (1.f + r + 10.f * AB) * (1.f + j + 100.f * b)) ++bad;
+        }
+    printf("cbsz = 4, abid = %2d: every block uses block %2d's A rows: %s (%d mismatches)\n", AB, AB, bad ? "NO" : "yes", bad);
+    return bad;
+}
 template <int NACC, int NFMA>
 __global__ __launch_bounds__(256) void cyc(float* out, unsigned long long* st, int iters, float a, float b) {
     f4 acc[NACC];
@@ -58,6 +80,7 @@ int main() {
         }
     printf("4x4x1_16B hypothesis %s (%d mismatches)\n", bad ? "WRONG" : "holds: A lane = 4 b + row, B lane = 4 b + col, D vgpr r of lane 4 b + j = block b row r col j", bad);
     for (int lane : {0, 1, 4, 5, 63}) { printf("lane %2d:", lane); for (int v = 0; v < 4; ++v) printf(" %.0f", h[lane * 4 + v]); printf("\n"); }
+    check_bcast<0>(d); check_bcast<3>(d); check_bcast<15>(d);
     run<1, 0>("1 accumulator (dependent chain)", d, st, 1);
     run<2, 0>("2 accumulators", d, st, 1);
     run<4, 0>("4 accumulators", d, st, 1);

@@ -185,6 +185,16 @@ std::vector<float> pack_conv_groups(const std::vector<double>& w, int cout, int 
     return out;
 }
 
+// folded conv [cout][cin][3][3] -> [oc group of 4][k][oc 4], k = tap * cin + channel, zero-padded to a multiple of 16: the A operands
+// of the 4 x 4-block MFMA form (vt_head3.h SeqConvQ) -- lane l of register kg holds output channel l & 3 at k = 16 kg + (l >> 2)
+void pack_conv_quads(const std::vector<double>& w, int cout, int cin, float* dst) {
+    const int kp = vth::kpad16(cin);
+    for (int g = 0; g < cout / 4; ++g)
+        for (int k = 0; k < kp; ++k)
+            for (int oc = 0; oc < 4; ++oc)
+                dst[((size_t)g * kp + k) * 4 + oc] = k < 9 * cin ? (float)w[((size_t)(4 * g + oc) * cin + k % cin) * 9 + k / cin] : 0.f;
+}
+
 // folded conv [cout][cin][3][3] -> MFMA A-operand images [oc_tile][chunk][64 lanes][4] for the
 // implicit GEMM of vt_head.h: element r of lane l of (ot, c) = w[oc = 16 ot + (l & 15)][ic = 4 icq + r][tap]
 // with quad Q = 4 c + (l >> 4), (tap, icq) = divmod(Q, cin / 4); zero beyond cout or 9 * cin / 4 quads.
@@ -1221,6 +1231,8 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             std::vector<double> w, b;
             if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, chans[i + 1], chans[i], w, b))) return rc;
             pack_conv_image(w, chans[i + 1], chans[i], dst + woff[i]);
+            if (i == 2) pack_conv_quads(w, 8, 16, dst + vth::O_W3Q);
+            if (i == 3) pack_conv_quads(w, 4, 8, dst + vth::O_W4Q);
 #ifndef VT_F16
             {
                 const int woff3[4] = {vth3::O3_W1, vth3::O3_W2, vth3::O3_W3, vth3::O3_W4};

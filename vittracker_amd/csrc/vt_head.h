@@ -41,7 +41,11 @@ constexpr int O_W4 = O_B3 + 16;
 constexpr int O_B4 = O_W4 + ntiles(4) * nchunks(8) * 256;
 constexpr int O_W5 = O_B4 + 16;   // [2][4] (ctr uses row 0)
 constexpr int O_B5 = O_W5 + 8;    // 2 (+2 pad)
-constexpr int TOWER_STRIDE = O_B5 + 4;
+// conv3 / conv4 once more for the 4 x 4-block MFMA form of vt_head3.h (SeqConvQ): [oc group of 4][k = (tap, channel), padded to 16][oc 4]
+constexpr int kpad16(int cin) { return (9 * cin + 15) / 16 * 16; }
+constexpr int O_W3Q = O_B5 + 4;
+constexpr int O_W4Q = O_W3Q + (8 / 4) * kpad16(16) * 4;
+constexpr int TOWER_STRIDE = O_W4Q + (4 / 4) * kpad16(8) * 4;
 static_assert(TOWER_STRIDE % 4 == 0 && O_W2 % 4 == 0 && O_W3 % 4 == 0 && O_W4 % 4 == 0, "16B alignment");
 
 template <int F>

@@ -422,8 +422,8 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------ head_seq3 (F = 16)
 // The sequential head of vt_head.h (one workgroup per frame runs the three towers in turn on ONE staged input map) with conv1 --
 // 70 % of a tower's MACs -- as three-piece bf16 products.  Only the INPUT map is held as pieces (tokens are split once, at staging,
-// and read by three towers): with conv1's output as pieces too the maps would need 190 KB.  conv1 writes fp32, conv2-4 are
-// vt_head.h's fp32-MFMA layers unchanged.  LDS: input pieces 94.5 KB + m1 42 KB + m2 21 KB + the score plane 1 KB = 158.5 KB; the
+// and read by three towers): with conv1's output as pieces too the maps would need 190 KB.  conv1 writes fp32, conv2 is vt_head.h's
+// fp32-MFMA layer unchanged, conv3 / conv4 (8 and 4 output channels) run on the 4 x 4-block fp32 MFMA, which pads nothing (SeqConvQ).  LDS: input pieces 94.5 KB + m1 42 KB + m2 21 KB + the score plane 1 KB = 158.5 KB; the
 // decode gathers size / offset at its two winning pixels from the global maps the workgroup has just written.
 using G16 = vth::Geo<16>;
 constexpr int SEQ3_IN_E = 3 * (C / 4) * G16::NPIX;                                         // uint2 entries
@@ -518,6 +518,71 @@ struct SeqConv1 {
     }
 };
 
+// conv3 (16 -> 8) and conv4 (8 -> 4) of the sequential head on v_mfma_f32_4x4x1_16B_f32 (sixteen independent 4 x 4 blocks, K = 1):
+// on the 16 x 16 MFMA these layers fill 8 and 4 of the 16 output rows; here a block's rows are ONE group of four output channels
+// and its columns four pixels, so nothing is padded: a wave covers 64 pixels (four map rows) x 4 output channels per instruction
+// (tools/src/probe_mfma4x4.hip: A from lane 4 b + row, B from lane 4 b + column, D register r of lane 4 b + j = row r, column j;
+// 8.8 cycles per instruction for one wave, and two waves of a SIMD both keep that rate).  Lane l supplies its own pixel's
+// activations (one ds_read_b128 = four k) and receives its pixel's four output channels = one float4 of the quad-planar map.
+// Weights use the instruction's A broadcast (cbsz = 4: every block multiplies by block `abid`'s rows): register kg of a lane holds
+// output channel l & 3 at k = 16 kg + (l >> 2), so a layer's whole [k][oc] image is 9 (conv3) / 5 (conv4) registers, loaded
+// a layer early by one coalesced dword load each.  Jobs = pixel groups (4) x output-channel groups: conv3 keeps all eight waves
+// busy, conv4 four (one per SIMD).  Four accumulators (k mod 4) keep dependent MFMAs 35 cycles apart (14.6 needed).
+template <int AB>
+__device__ __forceinline__ f4 mfma4x4_bcast(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, AB, 0); }
+__device__ __forceinline__ f4 mfma4x4_bcast(float a, float b, f4 c, int ab) {      // ab is a constant after unrolling
+    switch (ab) {
+        case 0: return mfma4x4_bcast<0>(a, b, c);   case 1: return mfma4x4_bcast<1>(a, b, c);
+        case 2: return mfma4x4_bcast<2>(a, b, c);   case 3: return mfma4x4_bcast<3>(a, b, c);
+        case 4: return mfma4x4_bcast<4>(a, b, c);   case 5: return mfma4x4_bcast<5>(a, b, c);
+        case 6: return mfma4x4_bcast<6>(a, b, c);   case 7: return mfma4x4_bcast<7>(a, b, c);
+        case 8: return mfma4x4_bcast<8>(a, b, c);   case 9: return mfma4x4_bcast<9>(a, b, c);
+        case 10: return mfma4x4_bcast<10>(a, b, c); case 11: return mfma4x4_bcast<11>(a, b, c);
+        case 12: return mfma4x4_bcast<12>(a, b, c); case 13: return mfma4x4_bcast<13>(a, b, c);
+        case 14: return mfma4x4_bcast<14>(a, b, c); default: return mfma4x4_bcast<15>(a, b, c);
+    }
+}
+template <int CIN, int COUT, int NW>
+struct SeqConvQ {
+    static constexpr int NQ = CIN / 4, NG = COUT / 4, NPG = 16 * 16 / 64, JOBS = NG * NPG, KP = vth::kpad16(CIN), NKR = KP / 16;
+    static_assert(CIN % 4 == 0 && COUT % 4 == 0 && JOBS <= NW, "shapes");
+    float wr[NKR];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ wq, int wave, int lane) {
+        if (wave >= JOBS) return;
+#pragma unroll
+        for (int kg = 0; kg < NKR; ++kg) wr[kg] = wq[(size_t)(wave % NG) * KP * 4 + kg * 64 + lane];
+    }
+    __device__ __forceinline__ void run(const f4* in_map, f4* out_map, const float* __restrict__ bias, int wave, int lane) {
+        if (wave >= JOBS) return;
+        const int g = wave % NG, pg = wave / NG;
+        const int p = 64 * pg + lane, y = p >> 4, x = p & 15;
+        const f4* in0 = in_map + y * G16::P + x;                                 // tap (0, 0) of this lane's pixel
+        f4 acc[4] = {ld4(bias + 4 * g), splat4(0.f), splat4(0.f), splat4(0.f)};
+        f4 bv[2][NQ];
+        auto fetch = [&](int tap, f4 (&bd)[NQ]) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int icq = 0; icq < NQ; ++icq) bd[icq] = in0[icq * G16::NPIX + dy * G16::P + dx];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fetch(0, bv[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) fetch(tap + 1, bv[(tap + 1) & 1]);
+#pragma unroll
+            for (int icq = 0; icq < NQ; ++icq)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = (tap * NQ + icq) * 4 + c;
+                    acc[c] = mfma4x4_bcast(wr[k >> 4], bv[tap & 1][icq][c], acc[c], k & 15);
+                }
+        }
+        f4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        out_map[g * G16::NPIX + G16::interior(y, x)] = v;
+    }
+};
+
 // grid B, NW * 64 threads.  Arguments as vth::head_seq_kernel + hw3 (the piece images; only conv1's are read).
 // DIAG: s_memtime stamps per wave and phase (VT_DBG_STAMPS, tools/head_stamps.py); compiled out of the production instantiation.
 template <int NW, int MAXP, bool DIAG = false>
@@ -548,8 +613,8 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     };
     stamp();
     vth::HeadConv<W1, 16, F, NW> c2;
-    vth::HeadConv<16, 8, F, NW> c3;
-    vth::HeadConv<8, 4, F, NW> c4;
+    SeqConvQ<16, 8, NW> c3;
+    SeqConvQ<8, 4, NW> c4;
     c1.prefetch(hw3 + O3_W1, wave, lane);      // first weight pass flies during the map set-up
     // (B,HW,C) tokens -> piece planes, once for the three towers (vit_dist.py:126-129): requested before the LDS is cleared so that
     // their L2 / HBM round trip runs under the clear and its barrier (stamps: 7.4 k cycles when requested after it, item by item)
@@ -580,20 +645,20 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
         stamp();
         if (!(VT_H3_SKIP & 1)) c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
         c2.prefetch(tw + vth::O_W2, wave, lane);    // (not before conv1: its working set is 200 registers)
-        c3.prefetch(tw + vth::O_W3, wave, lane);    // the later layers' first bursts are requested a layer early
+        c3.prefetch(tw + vth::O_W3Q, wave, lane);
         stamp();
         __syncthreads();
         stamp();
         if (!(VT_H3_SKIP & 2)) c2.run(m1, m2, tw + vth::O_W2, tw + vth::O_B2, wave, lane);
-        c4.prefetch(tw + vth::O_W4, wave, lane);
+        c4.prefetch(tw + vth::O_W4Q, wave, lane);
         stamp();
         __syncthreads();
         stamp();
-        if (!(VT_H3_SKIP & 8)) c3.run(m2, m1, tw + vth::O_W3, tw + vth::O_B3, wave, lane);
+        if (!(VT_H3_SKIP & 8)) c3.run(m2, m1, tw + vth::O_B3, wave, lane);
         stamp();
         __syncthreads();
         stamp();
-        if (!(VT_H3_SKIP & 8)) c4.run(m1, m2, tw + vth::O_W4, tw + vth::O_B4, wave, lane);
+        if (!(VT_H3_SKIP & 8)) c4.run(m1, m2, tw + vth::O_B4, wave, lane);
         if (t < 2) c1.prefetch(tw3 + TOWER3_STRIDE + O3_W1, wave, lane);   // the next tower's first pass
         stamp();
         __syncthreads();
