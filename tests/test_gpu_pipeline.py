@@ -73,7 +73,8 @@ def test_device_crop_random_boxes_on_odd_frame_sizes():
 def test_byte_load_crop_form_equals_the_host_crop():
     """vt_create's self test crops a known frame with the 8-byte unaligned-load kernel and with its byte-load twin and falls back
     to the twin on any difference (a device without unaligned access).  Here the twin is forced (VT_CROP_BYTES=1, read by the
-    self test; a process decides once, so this runs in a child) and held to the host statement bit for bit."""
+    self test; a process decides once, so this runs in a child) and held to the host statement bit for bit at the tracker's sizes
+    and at one that is a multiple of nothing."""
     import subprocess
     import sys
     code = r"""
@@ -81,15 +82,16 @@ import sys, numpy as np, torch
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import test_gpu_pipeline as T
 rs = np.random.RandomState(5)
-H, W, S = 37, 53, 64
+H, W = 37, 53
 boxes = [[rs.uniform(-10, W), rs.uniform(-10, H), rs.uniform(2, 40), rs.uniform(2, 40)] for _ in range(20)] + [[W - 3.5, H - 3.5, 3, 3], [0, 0, W, H], [W - 1, H - 1, 1, 1]]
 frames = rs.randint(0, 256, (len(boxes), H, W, 3)).astype(np.uint8)
 m = T._nat(B=len(boxes))
-crops, rf = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), 2.0, S, T.MEAN, T.STD)
-crops = crops.cpu().numpy()
-for b in range(len(boxes)):
-    want, want_rf = T._host_crop(frames[b], boxes[b], 2.0, S)
-    assert np.array_equal(crops[b], want), boxes[b]
+for S in (64, 128, 20):
+    crops, rf = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), 2.0, S, T.MEAN, T.STD)
+    crops = crops.cpu().numpy()
+    for b in range(len(boxes)):
+        want, want_rf = T._host_crop(frames[b], boxes[b], 2.0, S)
+        assert np.array_equal(crops[b], want), (S, boxes[b])
 print("BYTES-OK")
 """ % (REPO, os.path.join(REPO, "tests"))
     env = dict(os.environ, VT_CROP_BYTES="1")
