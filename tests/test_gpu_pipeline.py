@@ -190,10 +190,10 @@ def test_batched_tracker_equals_independent_plugin_trackers():
     np.testing.assert_array_equal(last["target_bbox"].cpu().numpy(), out["target_bbox"].numpy())
 
 
-@pytest.mark.parametrize("geom,B", [(128, 3), (256, 2), (128, 200)])
+@pytest.mark.parametrize("geom,B", [(128, 3), (256, 2), (128, 200), (256, 180)])
 def test_track_step_equals_its_three_calls(geom, B):
-    """vt_track_step (crop -> network on the cached template -> tail; the decode kernel runs the tail itself on the small-batch
-    path, the fused heads are followed by the tail kernel) == vt_crop + vt_forward + vt_update_state_record, bit for bit."""
+    """vt_track_step (crop -> network on the cached template -> tail, which the decoding lane of every head form runs itself: the
+    decode kernel on the small-batch path, the fused heads at 200) == vt_crop + vt_forward + vt_update_state_record, bit for bit."""
     import torch
     from vittracker_amd import native, synth
     m = native.Model(geom // 2, geom, max_batch=B)

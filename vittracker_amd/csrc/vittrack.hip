@@ -605,9 +605,9 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
         const vth3::u32x4* hw3 = reinterpret_cast<const vth3::u32x4*>(m->head3.p);
         if (m->head_fused < 0 ? Bf > 176 : m->head_fused != 0) {
             hipLaunchKernelGGL(vth3::head_fused3_kernel, dim3(B), dim3(768), vth3::FUSED3_LDS_BYTES, st, feat, m->head.p, hw3, m->window.p,
-                               score, size, offset, pred, hann, conf);
+                               score, size, offset, pred, hann, conf, tail ? *tail : TrackTail{}, tail ? 1 : 0);
             HIP_TRY(hipGetLastError());
-            return tail ? run_tail(st, hann, conf, B, *tail) : VT_OK;
+            return VT_OK;       // (the tracker's tail, if any, ran on the kernel's decoding lane)
         }
         hipLaunchKernelGGL(vth3::head_towers3_kernel, dim3(B, 3), dim3(256), vth3::TOWERS3_LDS_BYTES, st, feat, m->head.p, hw3, score, size,
                            offset);

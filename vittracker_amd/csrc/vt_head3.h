@@ -329,7 +329,8 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
                                                           const u32x4* __restrict__ hw3, const float* __restrict__ window,
                                                           float* __restrict__ score, float* __restrict__ size,
                                                           float* __restrict__ offset, float* __restrict__ pred,
-                                                          float* __restrict__ hann, float* __restrict__ conf) {
+                                                          float* __restrict__ hann, float* __restrict__ conf, TrackTail tail,
+                                                          int has_tail) {      // has_tail: the decoding lane also runs the tracker's tail (vt_track_step)
     constexpr int F = 8;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     u32x2* in_map = reinterpret_cast<u32x2*>(sm);
@@ -408,11 +409,15 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
                 pred[b * 4 + 2] = sz[i0];
                 pred[b * 4 + 3] = sz[n + i0];
             }
-            if (hann != nullptr && window != nullptr) {
-                hann[b * 4 + 0] = ((float)(i1 % F) + of[i1]) / fF;
-                hann[b * 4 + 1] = ((float)(i1 / F) + of[n + i1]) / fF;
-                hann[b * 4 + 2] = sz[i1];
-                hann[b * 4 + 3] = sz[n + i1];
+            if (window != nullptr && (hann != nullptr || has_tail)) {
+                const float hb[4] = {((float)(i1 % F) + of[i1]) / fF, ((float)(i1 / F) + of[n + i1]) / fF, sz[i1], sz[n + i1]};
+                if (hann != nullptr) {
+                    hann[b * 4 + 0] = hb[0];
+                    hann[b * 4 + 1] = hb[1];
+                    hann[b * 4 + 2] = hb[2];
+                    hann[b * 4 + 3] = hb[3];
+                }
+                if (has_tail) update_state_one(b, hb, v0, tail);
             }
             if (conf != nullptr) conf[b] = v0;
         }
