@@ -24,7 +24,8 @@
 
 #ifndef VT_F16
 #ifndef VT_H3_SKIP
-#define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs (head_seq3: no conv2), 4 = no weight loads in conv1, 8 = head_seq3: no conv3 / conv4
+#define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs (head_seq3: no conv2), 4 = no weight loads in conv1's steady state,
+                           // 8 = head_seq3: no conv3 / conv4, 16 = head_seq3: no activation reads in conv1's steady state
 #endif
 namespace vth3 {
 
@@ -495,12 +496,12 @@ struct SeqConv1 {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const int n = p + 1 < NPASS ? MAXP : LASTN;
-            if (p + 1 < NPASS) load_pass(wb, (p + 1) * MAXP, p + 2 < NPASS ? MAXP : LASTN, lane, a[(p + 1) & 1]);
+            if (p + 1 < NPASS && !(VT_H3_SKIP & 4)) load_pass(wb, (p + 1) * MAXP, p + 2 < NPASS ? MAXP : LASTN, lane, a[(p + 1) & 1]);
 #pragma unroll
             for (int k = 0; k < MAXP; ++k) {
                 if (k >= n) break;
                 const int cp = p * MAXP + k;
-                if (cp + 1 < NCP) {
+                if (cp + 1 < NCP && !(VT_H3_SKIP & 16)) {
                     read_b(cp + 1, b[(cp + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);        // keep the next pair's reads ahead of this pair's MFMAs
                 }
