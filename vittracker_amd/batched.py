@@ -202,11 +202,9 @@ class BatchedVitTracker:
                 r = self._records(rec, host)
                 return {"target_bbox": r[0, :, :4], "confidence": r[0, :, 4].float()}
             return {"target_bbox": self.states, "confidence": self.out.conf}
-        # a caller-owned device tensor (a new address every call would mean a new capture every call): eager launches
-        self.nat.crop(fr, self.states, self.params.search_factor, self.params.search_size, self.mean, self.std,
-                      out=self.x, resize_factor=self.rf)
-        self.graph.launch()
-        self.nat.update_state(self.out.hann_boxes, self.rf, self.states, self.params.search_size, H, W, margin=10)
+        # a caller-owned device tensor (a new address every call would mean a new capture every call): eager launches, as ONE library
+        # call (vt_track_step: crop -> network on the cached template with the state update on the head's decoding lane)
+        self.nat.track_step(fr, self.states, self.params.search_factor, self.mean, self.std, self.x, self.rf, self.out, margin=10)
         if sync:
             return {"target_bbox": self.states.cpu(), "confidence": self.out.conf.cpu()}
         return {"target_bbox": self.states, "confidence": self.out.conf}
