@@ -2,5 +2,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4s; rm -rf $O; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_tracker.py tests/test_gpu_harness.py -m gpu -q -x 2>&1 | tail -4 | tee $O/pytest.txt
-for cfg in vit_48_h32_g128 vit_48_h32_noKD; do timeout 600 python tracking/track_batch_demo.py --config $cfg --batch 256 --frames 400 2>&1 | grep -v amdgpu.ids | grep "frames already" | tee -a $O/demo.txt; done
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_variants.py tests/test_gpu_pipeline.py tests/test_gpu_f16cache.py -m gpu -q -x 2>&1 | tail -4 | tee $O/pytest.txt
+timeout 300 python tools/race_check.py --geom G256 --B 256 2>&1 | grep -v amdgpu.ids | tail -2
+timeout 300 python bench.py --geom G256 --no-cpu --no-extra 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('G256', d['value'], d['ms_per_step'])"

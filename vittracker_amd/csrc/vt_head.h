@@ -487,14 +487,17 @@ __device__ __forceinline__ void seq_decode(const float* outs, const float* sz, c
     if (i1 >= n) i1 = 0;
     if (lane == 0) {
         const float fF = (float)F;
+        // size / offset may be the global maps other waves of this workgroup have just written: read them at agent scope (from L2,
+        // never from a line this CU's vector cache might hold), whatever the barrier in front of this call already guarantees
+        auto g = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         if (pred != nullptr) {
-            pred[b * 4 + 0] = ((float)(i0 % F) + of[i0]) / fF;
-            pred[b * 4 + 1] = ((float)(i0 / F) + of[n + i0]) / fF;
-            pred[b * 4 + 2] = sz[i0];
-            pred[b * 4 + 3] = sz[n + i0];
+            pred[b * 4 + 0] = ((float)(i0 % F) + g(of + i0)) / fF;
+            pred[b * 4 + 1] = ((float)(i0 / F) + g(of + n + i0)) / fF;
+            pred[b * 4 + 2] = g(sz + i0);
+            pred[b * 4 + 3] = g(sz + n + i0);
         }
         if (window != nullptr && (hann != nullptr || has_tail)) {
-            const float hb[4] = {((float)(i1 % F) + of[i1]) / fF, ((float)(i1 / F) + of[n + i1]) / fF, sz[i1], sz[n + i1]};
+            const float hb[4] = {((float)(i1 % F) + g(of + i1)) / fF, ((float)(i1 / F) + g(of + n + i1)) / fF, g(sz + i1), g(sz + n + i1)};
             if (hann != nullptr) {
                 hann[b * 4 + 0] = hb[0];
                 hann[b * 4 + 1] = hb[1];
