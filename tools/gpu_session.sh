@@ -1,0 +1,73 @@
+#!/bin/bash
+# One parameterised GPU-box session script (round 5; replaces the one-shot gpu_r4_*.sh family).
+#   gpurun --timeout N -- bash tools/gpu_session.sh <task> [task ...]
+# Every task writes under gpurun_out/s5/<task>/ and prints a short summary.  Tasks:
+#   vitb_tests      tests/test_gpu_vitb.py (+ the ViT-Base variants test)
+#   vitb_ab         tools/ab_vitb.py: in-tree library against build_variants/*.so, interleaved, one box
+#   vitb_nofold     the ViT-Base tests and one timing with VB_LN_FOLD=0 (separate LayerNorm kernel)
+#   vitb_prof       rocprofv3 kernel stats of tools/vitb_time.py
+#   vitb_traffic    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/vitb_time.py -> traffic json
+#   tests           the whole -m gpu suite
+#   quick48         parity subset + per-stage times of the vit_48 path (G128, G256)
+#   ab48 [names]    tools/ab_stages.py against build_variants/*.so
+#   bench           python bench.py (the driver's line) -> bench.json
+#   bench_noextra   python bench.py --no-extra
+#   race            tools/race_check.py at G128 and G256
+#   trackstep       tracking/track_batch_demo.py --batch 256 at both geometries
+#   generic         tests/test_gpu_generic.py
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+export TMPDIR=/tmp
+for task in "$@"; do
+  O=$R/gpurun_out/s5/$task; rm -rf $O; mkdir -p $O
+  echo "=== $task"
+  case $task in
+    vitb_tests)
+      timeout 1200 python -m pytest tests/test_gpu_vitb.py tests/test_gpu_variants.py -k vitb -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt
+      tail -5 $O/pytest.txt ;;
+    vitb_ab)
+      timeout 1500 python tools/ab_vitb.py --rounds 2 > $O/ab.txt 2>&1; cat $O/ab.txt ;;
+    vitb_nofold)
+      VB_LN_FOLD=0 timeout 900 python -m pytest tests/test_gpu_vitb.py -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt
+      tail -3 $O/pytest.txt
+      VB_LN_FOLD=0 timeout 600 python tools/ab_vitb.py --rounds 1 --only cur > $O/ab.txt 2>&1; cat $O/ab.txt ;;
+    vitb_prof)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/vitb_time.py > $O/prof.log 2>&1)
+      python3 - $O/prof <<'P'
+import csv,sys,glob
+for f in glob.glob(sys.argv[1]+'/*/*kernel_stats.csv'):
+    rows=list(csv.DictReader(open(f)))
+    tot=sum(float(r['TotalDurationNs']) for r in rows)
+    for r in rows:
+        if float(r['TotalDurationNs'])/tot>0.003: print('  %-70s calls %5s avg %8.1f us  %5.1f%%' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3, 100*float(r['TotalDurationNs'])/tot))
+P
+      find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete ;;
+    vitb_traffic)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        (cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $R/tools/vitb_time.py > $O/$c.log 2>&1)
+      done
+      python3 tools/pmc_traffic.py $O/FETCH_SIZE $O/WRITE_SIZE > $O/traffic.json 2> $O/traffic.err || tail -3 $O/traffic.err
+      head -c 3000 $O/traffic.json
+      find $O -name "*.db" -delete ;;
+    tests)
+      timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -6 $O/pytest.txt ;;
+    quick48)
+      timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_variants.py -m gpu -x -q -k "not vitb" > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -4 $O/pytest.txt
+      timeout 600 python tools/ab_stages.py --only cur > $O/stages.txt 2>&1; cat $O/stages.txt ;;
+    ab48)
+      timeout 1500 python tools/ab_stages.py > $O/ab.txt 2>&1; cat $O/ab.txt ;;
+    bench)
+      timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.err; head -c 2500 $O/bench.json ;;
+    bench_noextra)
+      timeout 600 python bench.py --no-extra > $O/bench.json 2> $O/bench.err; head -c 2500 $O/bench.json ;;
+    race)
+      timeout 600 python tools/race_check.py > $O/g128.txt 2>&1; tail -3 $O/g128.txt
+      timeout 600 python tools/race_check.py --geom G256 --B 256 > $O/g256.txt 2>&1; tail -3 $O/g256.txt ;;
+    trackstep)
+      timeout 600 python tracking/track_batch_demo.py --batch 256 > $O/g128.txt 2>&1; tail -4 $O/g128.txt
+      timeout 600 python tracking/track_batch_demo.py --batch 256 --geom G256 > $O/g256.txt 2>&1; tail -4 $O/g256.txt ;;
+    generic)
+      timeout 900 python -m pytest tests/test_gpu_generic.py -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -5 $O/pytest.txt ;;
+    *) echo "unknown task $task" ;;
+  esac
+done

@@ -14,17 +14,31 @@
 // conflict-free); the swizzle is applied to the per-lane SOURCE address and to the fragment read, the LDS destination
 // of a DMA stays lane-linear.
 //
-// Pipeline (256 x 256 tile): FOUR LDS stages of one 32-deep k-step each (4 x 32 KiB); the DMAs of k-steps t+1 .. t+3 are
-// in flight while step t is multiplied -- 96 KiB per CU, which is what it takes to cover the HBM / Infinity-Cache
-// latency of a streamed left operand (measured: with one 64-deep k-tile in flight the fc2 GEMM, whose 503 MB operand
-// comes from HBM, ran at 2.9 us per k-tile against 1.7 us for the L2-resident conv1 operand).  Per step: a COUNTED
-// s_waitcnt vmcnt(8) (the two younger steps stay in flight; never 0 inside a tile), one raw s_barrier, the DMA of step
-// t+3 into the stage step t-1 just vacated, 12 ds_read_b128 and 32 MFMAs per wave.  The narrow tile (256 x 64, head
-// convs 2-4) keeps the simple two-buffer 64-deep loop.
+// Pipeline (256 x 256 tile): the software-pipelined k-loop below (two LDS stages of one 64-deep k-tile, one DMA piece per
+// group of 8 MFMAs, two barriers per k-tile, counted vmcnt).  The narrow tile (256 x 64, head convs 2-4) keeps a simple
+// two-buffer 64-deep loop.  (Rounds 2-3 also carried a 4-stage, a whole-line two-stage and a phase-interleaved form of the wide
+// loop; all measured slower -- NOTES_r1_r3.md -- and were removed in round 5.)
 //
 // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs, so id -> (id % 8) * per_xcd +
 // id / 8 gives every XCD a contiguous run of tiles, n fastest: the X panel of a tile row is fetched into that XCD's L2
 // once and re-used by all its column tiles.
+//
+// Per-feature bias and per-token LayerNorm factor (round 5).  Neither lives in registers across the k-loop: behind a tile's
+// epilogue every wave requests the NEXT tile's 64 bias values and (LayerNorm-folded GEMMs) 128 per-token rstd values by
+// three 4-byte LDS-DMA instructions into the head of its own 4 KiB epilogue staging area, which nothing else touches until
+// that tile's epilogue; the wait in front of the tile's first k-tile covers them.  The accumulators start at zero.
+//
+// LayerNorm folded into the GEMM that consumes it (qkv, fc1; lib/models/ostrack/vit.py:88-90):
+//     LN(x) W^T + b = rstd_m * (x (W diag(g) (I - 11^T / K))^T) + (b + W beta)
+// i.e. the k-centred, gamma-scaled weight rows W' (folded in fp64 at vt_load_weights) absorb the mean subtraction, the GEMM
+// reads the RAW residual row rounded to bf16, and the epilogue multiplies by the row's rstd.  The GEMM that PRODUCES a residual
+// row (patch embedding, proj, fc2: EPI_PATCH / EPI_RESID) writes that bf16 copy next to its f32 read-modify-write and, per
+// (row, 64-column wave slice), the slice's (sum, centred sum of squares); vbm::ln_finalize_kernel merges the 12 slices of a
+// row (Chan's update) into rstd.  What this removes: the LayerNorm kernel's pass over the residual stream (252 MB read + 126 MB
+// written per LayerNorm at B = 256; 24 of 25 launches).  What it costs in accuracy: the common mode of a row is rounded with
+// the row instead of being subtracted first -- the error of the product grows by sqrt(1 + mean^2 / var) of the row
+// (tools/vitb_lnfold_emul.py: identical to the unfolded form at the fixtures' mean^2 / var << 1; 2.3x at mean = 2 std).
+// VB_LN_FOLD=0 (read at vt_create) keeps the separate LayerNorm kernel and unfolded weights.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,9 +47,6 @@
 
 #include "vt_common.h"
 
-#ifndef VB_GEMM_LINE2
-#define VB_GEMM_LINE2 1
-#endif
 #ifndef VB_SWP_NO_MFMA
 #define VB_SWP_NO_MFMA 0     // timing experiments only: the software-pipelined k-loop without its MFMAs (wrong results)
 #endif
@@ -50,15 +61,6 @@
 #endif                       //    the transposed V stores, which always carry it: v projection 100 -> 92 us)
 #ifndef VB_SWP_HALFISSUE
 #define VB_SWP_HALFISSUE 0   // 1: only the wm = 0 waves issue the DMA instructions (two per slot)
-#endif
-#ifndef VB_SWP_SPLIT
-#define VB_SWP_SPLIT 0       // 1: a k-tile's 8 DMA instructions per wave go out 4 + 4 in S7 / S8 instead of all behind the barrier
-#endif
-#ifndef VB_GEMM_SWP
-#define VB_GEMM_SWP 1        // wide tile: the software-pipelined k-loop, two barriers per k-tile (below); 0 = the phase-interleaved one
-#endif
-#ifndef VB_GEMM_PH8
-#define VB_GEMM_PH8 1        // wide tile: the phase-interleaved schedule with two staggered wave groups (below) instead of one burst per k-tile
 #endif
 
 namespace vbg {
@@ -104,6 +106,11 @@ struct Args {
                           // 32 concurrent tiles of an XCD are ~rb rows x 32 / rb columns); 0 / 1 = row-major
     int desync_ticks;     // > 0: workgroup phase groups -- group g = (blockIdx.x / 8) % desync_groups starts g * desync_ticks / desync_groups
     int desync_groups;    // ticks of the 100 MHz clock late, so the CUs' epilogues (HBM) and k-loops (MFMA) do not all coincide
+    // LayerNorm folded into the consuming GEMM (header comment)
+    const float* rstd;    // consumer (BF16 / VT / GELU): [M] per-row 1 / sqrt(var + eps); nullptr = plain bias epilogue
+    bf16* xb;             // producer (PATCH / RESID): [M][N] bf16 copy of the rows just written to `resid`; nullptr = none
+    f2* stats;            // producer: [tiles_n * WN][ldstats] per-row (sum, centred sum of squares) of each 64-column wave slice
+    int ldstats;
     int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
                           // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
                           // 4 = no MFMAs, 8 = no epilogue, 16 = no W staging, 32 = no X staging (wide tile)
@@ -129,6 +136,21 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f4 v) {
     return bf16x4{lo.x, lo.y, hi.x, hi.y};
 }
 
+__device__ __forceinline__ f4 fma4(f4 a, f4 b, f4 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// sum over the 16 lanes of a DPP row (lane & 15 varies), result in every lane: two quad permutes, row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    v += dpp_f<0x140>(v);     // row_mirror
+    return v;
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     static_assert(WM * WN == NWAVES, "8 waves");
@@ -139,14 +161,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     constexpr int NSX = SX / NWAVES;
     constexpr int BUF_BYTES = (SX + SW) * 1024;
     constexpr bool WIDE = (BM / 16) % NWAVES == 0 && (BN / 16) % NWAVES == 0;      // the 256 x 256 tile
-    // Two fill paths for the wide tile (A/B-tested on hardware; LINE2 is the shipped one):
-    //   LINE2: two stages of one 64-deep k-tile; a DMA piece is 8 rows x 128 B, i.e. WHOLE cache lines (half the L2 requests
-    //          per byte of the 16-row x 64-byte pieces), XOR-swizzled by row (chunk ^ row): conflict-free ds_read_b128.
-    //   PIPE4: four stages of one 32-deep k-step in 16-row x 64-byte pieces (st_16x32), counted vmcnt.
-    constexpr bool SWP = WIDE && VB_GEMM_SWP;
-    constexpr bool PH8 = WIDE && VB_GEMM_PH8 && !SWP;
-    constexpr bool LINE2 = WIDE && VB_GEMM_LINE2 && !PH8 && !SWP;
-    constexpr bool PIPE4 = WIDE && !LINE2 && !PH8 && !SWP;
+    constexpr bool SWP = WIDE;
     constexpr int EP_OFF = 2 * BUF_BYTES;                                           // epilogue staging: 8 waves x 4 KiB behind the stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -217,20 +232,27 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     };
 
     f4 acc[TN][TM];
-    const int q4 = (lane >> 4) * 4, l15 = lane & 15;
-    // Bias: the accumulators START at the bias (loaded a tile ahead, so no load of the epilogue ever waits while the next
-    // tile's DMA is in flight -- hipcc answers such a wait with vmcnt(0), which would serialise every store behind it).
     // Normal tiles: lane holds n = nb + 4q + {0..3} of token m = mb + (lane & 15); EPI_VT: tokens mb + 4q + {0..3} of feature
     // n = nb + (lane & 15).
-    f4 bias_cur[TN], bias_nxt[TN];
-    auto load_bias = [&](int n0, f4 (&bv)[TN]) {
+    // Per-feature bias / per-token rstd of the NEXT tile -> the head of this wave's epilogue staging area (header comment):
+    // ep[0, 256) = bias of the wave's 64 features, ep[256, 256 + 64 TM) = rstd of its 16 TM tokens.  Rows / columns beyond M / N
+    // read a valid element (result unused).
+    constexpr bool LNC = EPI == EPI_BF16 || EPI == EPI_VT || EPI == EPI_GELU;      // may consume a folded LayerNorm
+    char* const ep = smem + EP_OFF + w * 4096;
+    auto stage_vec = [&](int m0, int n0) {
+        int n = n0 + wn * 64 + lane;
+        n = n < a.N ? n : a.N - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + n),
+                                         (__attribute__((address_space(3))) void*)ep, 4, 0, 0);
+        if constexpr (LNC) {
+            if (a.rstd) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            if constexpr (EPI == EPI_VT) {
-                bv[i] = splat4(bias[n0 + (wn * TN + i) * 16 + l15]);
-            } else {
-                const int n = n0 + (wn * TN + i) * 16 + q4;
-                bv[i] = n < a.N ? ld4(bias + n) : splat4(0.f);
+                for (int h = 0; h < TM * 16 / 64; ++h) {
+                    int m = m0 + wm * TM * 16 + h * 64 + lane;
+                    m = m < a.M ? m : a.M - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rstd + m),
+                                                     (__attribute__((address_space(3))) void*)(ep + 256 + h * 256), 4, 0, 0);
+                }
             }
         }
     };
@@ -240,7 +262,6 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
     // those cost 12 us per 256 x 256 tile, a third of the K = 768 GEMMs).  Chunks are XOR-swizzled by row so the column-wise
     // writes spread over the banks.  CHECK = false on tiles wholly inside M (all but the last tile row): no per-store branch.
     static_assert(TN == 4, "a wave's sub-tile is 64 output features wide");
-    char* const ep = smem + EP_OFF + w * 4096;
     auto epilogue_impl = [&](int m0, int n0, auto check) {
         constexpr bool CHECK = decltype(check)::value;
         // per-lane epilogue addresses come from a FRESH copy of the lane index: computed from the kernel's own `lane` they are
@@ -249,14 +270,24 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
         asm volatile("" : "+v"(lane_e));
         const int lane = lane_e, l15 = lane & 15, q4 = (lane >> 4) * 4;
         const int mw = m0 + wm * TM * 16, nw = n0 + wn * 64;           // this wave's sub-tile origin
+        // this tile's bias (and rstd) out of the staging area's head, BEFORE the first staging write overwrites it (DS
+        // operations of one wave execute in order)
         if constexpr (EPI == EPI_VT) {
             // swapped tile: features on lanes.  Chunk = 16 features x 128 tokens (256-byte rows)
             static_assert(EPI != EPI_VT || TM == 8, "128 tokens per row");
+            float bs[TN];
+            f4 rs[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) bs[i] = *reinterpret_cast<const volatile float*>(ep + (i * 16 + l15) * 4);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) rs[j] = a.rstd ? *reinterpret_cast<const f4a*>(ep + 256 + (j * 16 + q4) * 4) : splat4(1.f);
+            lds_fence();
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
-                    *reinterpret_cast<bf16x4a*>(ep + l15 * 256 + (((j * 2 + (q4 >> 3)) ^ l15) << 4) + (q4 & 4) * 2) = to_bf16x4(acc[i][j]);
+                    *reinterpret_cast<bf16x4a*>(ep + l15 * 256 + (((j * 2 + (q4 >> 3)) ^ l15) << 4) + (q4 & 4) * 2) =
+                        to_bf16x4(fma4(acc[i][j], rs[j], splat4(bs[i])));
                 lds_fence();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -273,12 +304,18 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             return;
         }
         if (nw >= a.N) return;                                           // W rows beyond N are zero padding (BN = 64, N = 32)
+        f4 bs[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) bs[i] = *reinterpret_cast<const f4a*>(ep + (i * 16 + q4) * 4);
         if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
-            // f32 residual stream: chunk = 16 rows x 256 B; read-modify-write in whole rows, loads before stores
+            lds_fence();
+            // f32 residual stream: chunk = 16 rows x 256 B; read-modify-write in whole rows, loads before stores.  Next to it
+            // (LayerNorm folded into the next GEMM): the rows' bf16 copy and, per row, this wave's 64-column (sum, centred M2)
+            const int tn = n0 / BN;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j];
+                for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j] + bs[i];
                 f4 old[4];
                 const int ch = lane & 15, r0 = lane >> 4;
 #pragma unroll
@@ -295,9 +332,18 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 for (int t = 0; t < 4; ++t) {
                     const int row = 4 * t + r0, m = mw + j * 16 + row;
                     const f4 v = *reinterpret_cast<const f4a*>(ep + row * 256 + ((ch ^ row) << 4));
-                    if (!CHECK || m < a.M) {
-                        if (VB_EPI_NT) st4_nt(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
-                        else st4(a.resid + (size_t)m * a.N + nw + ch * 4, old[t] + v);
+                    const f4 nv = old[t] + v;
+                    const bool ok = !CHECK || m < a.M;
+                    if (ok) {
+                        if (VB_EPI_NT) st4_nt(a.resid + (size_t)m * a.N + nw + ch * 4, nv);
+                        else st4(a.resid + (size_t)m * a.N + nw + ch * 4, nv);
+                    }
+                    if (a.xb) {
+                        if (ok) *reinterpret_cast<bf16x4*>(a.xb + (size_t)m * a.N + nw + ch * 4) = to_bf16x4(nv);
+                        const float s = row16_sum(hsum4(nv));
+                        const f4 d = nv - splat4(s * (1.0f / 64.0f));
+                        const float m2 = row16_sum(hsum4(d * d));
+                        if (ok && ch == 0) a.stats[(size_t)(tn * WN + wn) * a.ldstats + m] = f2{s, m2};
                     }
                 }
                 lds_fence();
@@ -305,6 +351,16 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             return;
         }
         // bf16 outputs: chunk = 32 rows x 128 B
+        float rs[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) rs[j] = 1.f;
+        if constexpr (LNC) {
+            if (a.rstd) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) rs[j] = *reinterpret_cast<const volatile float*>(ep + 256 + (j * 16 + l15) * 4);
+            }
+        }
+        lds_fence();
         bf16* obase = static_cast<bf16*>(a.out);
         int ncol = nw;
         if constexpr (EPI == EPI_CONV) {
@@ -318,7 +374,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 const int row = jj * 16 + l15;
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
-                    f4 v = acc[i][2 * c + jj];
+                    f4 v = LNC ? fma4(acc[i][2 * c + jj], splat4(rs[2 * c + jj]), bs[i]) : acc[i][2 * c + jj] + bs[i];
                     if constexpr (EPI == EPI_GELU) v = gelu4(v);
                     if constexpr (EPI == EPI_CONV) v = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
                     *reinterpret_cast<bf16x4a*>(ep + row * 128 + (((i * 2 + (q4 >> 3)) ^ (row & 7)) << 4) + (q4 & 4) * 2) = to_bf16x4(v);
@@ -369,20 +425,16 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
     };
-    auto zero_acc = [&]() {          // accumulators start at the bias of their output features
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = bias_cur[i];
-    };
-    auto roll_bias = [&]() {
-#pragma unroll
-        for (int i = 0; i < TN; ++i) bias_cur[i] = bias_nxt[i];
+            for (int j = 0; j < TM; ++j) acc[i][j] = splat4(0.f);
     };
     int vb = blockIdx.x, m0, n0;
     if (vb >= nwg) return;
     tile_of(vb, m0, n0);
-    load_bias(n0, bias_cur);
+    stage_vec(m0, n0);
 
     if constexpr (SWP) {
         // ---- Software-pipelined k-loop, TWO barriers per k-tile, one DMA instruction per stage.  LDS as in the phase-interleaved
@@ -624,340 +676,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             }
             ktile(nk - 2, S0, T, Fa, Fa);
             ktile(nk - 1, S1, Fa, Fa, T);
-            if (more) load_bias(n0, bias_nxt);
             if (!(a.dbg & 8)) epilogue(cm0, cn0);
             if (!more) break;
-            roll_bias();
-        }
-    } else if constexpr (PH8) {
-        // ---- Phase-interleaved schedule (cdna_hip_programming.md "The 256^2 8-phase template", rebuilt for this tile).
-        // Two LDS stages of one 64-deep k-tile (64 KiB each) in whole-line pieces as LINE2; a k-tile is FOUR half-panels of
-        // 16 KiB: X rows 0-127 | X rows 128-255 | W rows 0-127 | W rows 128-255, each staged by all 8 waves with 2 DMA
-        // instructions per wave.  A k-tile is four phases; phase = {fragment reads of one accumulator quadrant + ONE half-panel
-        // DMA} | barrier | 16 MFMAs | barrier:
-        //     phase 1   reads X0 (8) + W0 (4)   Q(X0, W0)      stages X-lo (t + 1)
-        //     phase 2   reads W1 (4)            Q(X0, W1)      stages X-hi (t + 1)
-        //     phase 3   reads X1 (8)            Q(X1, W1)      stages W-lo (t + 2)   (every W fragment of tile t is in registers)
-        //     phase 4   (W0 kept)               Q(X1, W0)      stages W-hi (t + 2), then the ONE counted wait of the k-tile:
-        //                                                       vmcnt(4) = all but the two W halves of tile t + 2 have landed
-        // (X0 / X1 = the wave's token tiles 0-3 / 4-7, W0 / W1 = its feature tiles 0-1 / 2-3).  The wave groups wm = 0 (waves 0-3)
-        // and wm = 1 (waves 4-7: the SIMD partners) run one barrier apart: while one group's 16 MFMAs occupy the matrix pipe the
-        // other group issues its LDS reads and DMA.  LDS-DMA data is read one phase after the wait that retires it, behind a
-        // barrier every wave has passed after its own wait; a half-panel is re-staged no earlier than the phase after its last
-        // read, and every phase's reads are retired (lgkmcnt(0)) in front of its first barrier.
-        constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
-        constexpr int NQ = (PX + PW) / NWAVES;                        // 8 DMA instructions per wave and k-tile: i = 2 h, 2 h + 1 for half-panel h
-        static_assert(2 * STAGE_BYTES == EP_OFF && NQ == 8 && TM == 8 && TN == 4, "256 x 256 tile, 2 x 4 waves");
-        const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;
-        unsigned soff[NQ];
-        auto set_sources_p = [&](int m0, int n0) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int p = w + NWAVES * i;
-                if (i < NQ / 2) {
-                    int m = m0 + p * 8 + drow;
-                    m = m < a.M ? m : a.M - 1;
-                    unsigned base;
-                    if constexpr (AMODE == A_CONV) {
-                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                        base = (unsigned)(((b * P + y) * P + x) * a.C);
-                    } else {
-                        base = (unsigned)m * (unsigned)a.K;
-                    }
-                    soff[i] = base + dk;
-                } else {
-                    soff[i] = (unsigned)(n0 + (p - PX) * 8 + drow) * (unsigned)a.K + dk;
-                }
-            }
-        };
-        auto issue_half = [&](int kt, int h) {      // half-panel h (0: X-lo, 1: X-hi, 2: W-lo, 3: W-hi) of k-tile kt -> stage kt & 1
-            unsigned kx;
-            if constexpr (AMODE == A_CONV) {
-                const int per_tap = a.C / BK, tap = kt / per_tap, c0 = (kt - tap * per_tap) * BK, r = tap / 3, sx = tap - 3 * r;
-                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
-            } else {
-                kx = (unsigned)kt * BK;
-            }
-            char* st = smem + (kt & 1) * STAGE_BYTES;
-            if ((a.dbg & 16) && h >= 2) return;          // timing experiments: no W staging / no X staging (wrong results)
-            if ((a.dbg & 32) && h < 2) return;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = 2 * h + ii, p = w + NWAVES * i;
-                const bf16* g = h < 2 ? X + soff[i] + kx : W + soff[i] + (unsigned)kt * BK;
-                glds16(g, st + p * 1024 + lane * 16);
-            }
-        };
-        const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
-        const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
-        const int nk = a.K / BK;
-        bf16x8 fx[4][2], fw0[2][2], fw1[2][2];          // [tile][k-step]
-        auto read_x = [&](const char* st, int half) {
-            const char* xp = st + (wm * TM * 2 + half * 8) * 1024;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                fx[j][0] = *reinterpret_cast<const bf16x8*>(xp + j * 2048 + fk0);
-                fx[j][1] = *reinterpret_cast<const bf16x8*>(xp + j * 2048 + fk1);
-            }
-        };
-        auto read_w = [&](const char* st, int half, bf16x8 (&fw)[2][2]) {
-            const char* wp = st + (PX + wn * TN * 2 + half * 4) * 1024;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fw[i][0] = *reinterpret_cast<const bf16x8*>(wp + i * 2048 + fk0);
-                fw[i][1] = *reinterpret_cast<const bf16x8*>(wp + i * 2048 + fk1);
-            }
-        };
-        auto quadrant = [&](int xh, int wh, const bf16x8 (&fw)[2][2]) {     // 16 MFMAs: token tiles 4 xh .. + 3, feature tiles 2 wh, 2 wh + 1
-            __builtin_amdgcn_s_setprio(1);
-            if (!(a.dbg & 4)) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if constexpr (EPI == EPI_VT)
-                                acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j][kk], fw[i][kk], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
-                            else
-                                acc[2 * wh + i][4 * xh + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i][kk], fx[j][kk], acc[2 * wh + i][4 * xh + j], 0, 0, 0);
-                        }
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto phase_sync = [&]() {           // retire this phase's fragment reads, then the barrier in front of the MFMAs
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto phase_end = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        };
-        // tile prologue: k-tile 0 whole, the W halves of k-tile 1 (what phases 3 / 4 of "k-tile -1" would have staged)
-        auto prologue = [&]() {
-            issue_half(0, 0); issue_half(0, 1); issue_half(0, 2); issue_half(0, 3);
-            if (nk > 1) { issue_half(1, 2); issue_half(1, 3); }
-        };
-        set_sources_p((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-        prologue();
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (wm == 1) __builtin_amdgcn_s_barrier();          // the stagger: group 1 runs one barrier behind group 0
-        for (;;) {
-            zero_acc();
-            for (int kt = 0; kt < nk; ++kt) {
-                const char* st = smem + (kt & 1) * STAGE_BYTES;
-                // phase 1
-                read_w(st, 0, fw0);
-                __builtin_amdgcn_sched_barrier(0);
-                read_x(st, 0);
-                if (kt + 1 < nk) issue_half(kt + 1, 0);
-                phase_sync();
-                quadrant(0, 0, fw0);
-                phase_end();
-                // phase 2
-                read_w(st, 1, fw1);
-                if (kt + 1 < nk) issue_half(kt + 1, 1);
-                phase_sync();
-                quadrant(0, 1, fw1);
-                phase_end();
-                // phase 3
-                read_x(st, 1);
-                if (kt + 2 < nk) issue_half(kt + 2, 2);
-                phase_sync();
-                quadrant(1, 1, fw1);
-                phase_end();
-                // phase 4: the k-tile's one counted wait -- everything but the two W halves just staged has landed
-                if (kt + 2 < nk) {
-                    issue_half(kt + 2, 3);
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                phase_sync();
-                quadrant(1, 0, fw0);
-                phase_end();
-            }
-            // group 0 is one barrier ahead: it waits here for group 1's last phase, then both LDS stages are free
-            if (wm == 0) __builtin_amdgcn_s_barrier();
-            const int cm0 = m0, cn0 = n0;
-            vb += gridDim.x;
-            const bool more = vb < nwg;
-            if (more) {
-                tile_of(vb, m0, n0);
-                set_sources_p((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-                prologue();
-                load_bias(n0, bias_nxt);
-            }
-            if (!(a.dbg & 8)) epilogue(cm0, cn0);
-            if (!more) break;
-            roll_bias();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (wm == 1) __builtin_amdgcn_s_barrier();
-        }
-    } else if constexpr (LINE2) {
-        // ---- two stages of one 64-deep k-tile in whole-line pieces: [stage][X pieces BM/8 | W pieces BN/8] x 1 KiB,
-        // piece = 8 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ r
-        constexpr int PX = BM / 8, PW = BN / 8, STAGE_BYTES = (PX + PW) * 1024;
-        constexpr int NQ = (PX + PW) / NWAVES, NQX = PX / NWAVES;
-        static_assert(2 * STAGE_BYTES == EP_OFF, "stages end where the epilogue staging begins");
-        const int drow = lane >> 3, dk = ((lane & 7) ^ drow) * 8;       // DMA: row in piece, k element of this lane's 16 bytes
-        unsigned soff[NQ];
-        auto set_sources_l = [&](int m0, int n0) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int p = w + NWAVES * i;
-                if (i < NQX) {
-                    int m = m0 + p * 8 + drow;
-                    m = m < a.M ? m : a.M - 1;
-                    unsigned base;
-                    if constexpr (AMODE == A_CONV) {
-                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                        base = (unsigned)(((b * P + y) * P + x) * a.C);
-                    } else {
-                        base = (unsigned)m * (unsigned)a.K;
-                    }
-                    soff[i] = base + dk;
-                } else {
-                    soff[i] = (unsigned)(n0 + (p - PX) * 8 + drow) * (unsigned)a.K + dk;
-                }
-            }
-        };
-        auto issue_l = [&](int kt, char* st) {
-            unsigned kx;
-            if constexpr (AMODE == A_CONV) {
-                const int per_tap = a.C / BK, tap = kt / per_tap, c0 = (kt - tap * per_tap) * BK, r = tap / 3, sx = tap - 3 * r;
-                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
-            } else {
-                kx = (unsigned)kt * BK;
-            }
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int p = w + NWAVES * i;
-                const bf16* g = i < NQX ? X + soff[i] + kx : W + soff[i] + (unsigned)kt * BK;
-                glds16(g, st + p * 1024 + lane * 16);
-            }
-        };
-        // fragment of 16-row tile T, k-step kk: row r16 = lane & 15 -> piece 2T + (r16 >> 3), row r16 & 7, chunk (4 kk + q) ^ row
-        const int r7 = lane & 7, fbase = ((lane & 15) >> 3) * 1024 + r7 * 128;
-        const int fk0 = fbase + ((((lane >> 4)) ^ r7) << 4), fk1 = fbase + (((4 + (lane >> 4)) ^ r7) << 4);
-        const int nk = a.K / BK;
-        set_sources_l((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-        issue_l(0, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (;;) {
-            zero_acc();
-            for (int kt = 0; kt < nk; ++kt) {
-                char* cur = smem + (kt & 1) * STAGE_BYTES;
-                if (kt + 1 < nk) issue_l(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
-                if (!(a.dbg & 4)) {
-                    mfma_step(cur + (wm * TM * 2) * 1024 + fk0, cur + (PX + wn * TN * 2) * 1024 + fk0, 2048);
-                    mfma_step(cur + (wm * TM * 2) * 1024 + fk1, cur + (PX + wn * TN * 2) * 1024 + fk1, 2048);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            // Every wave has passed the barrier that ends the last k-tile: both stages are free; the next tile's first k-tile
-            // and bias are requested before the epilogue.  Measured and rejected on this loop (B = 256, us per launch):
-            //   * requesting TWO k-tiles here + a counted vmcnt that leaves the epilogue's stores in flight: qk 205 -> 237, v 107 -> 139
-            //   * the DMA pieces issued one by one between groups of 8 MFMAs (sched_barrier-pinned) instead of as a burst:
-            //     qk 205 -> 213, fc1 447 -> 448 (and 16-20 B of scratch)
-            //   * PIPE4 with waves 4-7 issuing their DMA share after their MFMAs (stagger): qk 216, fc1 473, conv1 625
-            // What the VB_DBG experiments say (profiles/r2_vitb_timing_experiments.txt): the DMA pipeline alone runs at
-            // ~48 GB/s per CU (1.4 us per 64 KiB k-tile) whatever the piece shape or depth, the MFMAs alone need 0.85 us, and
-            // together they take 1.8 us: the two do not overlap well inside one instruction stream per wave.
-            const int cm0 = m0, cn0 = n0;
-            vb += gridDim.x;
-            const bool more = vb < nwg;
-            if (more) {
-                tile_of(vb, m0, n0);
-                set_sources_l((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-                issue_l(0, smem);
-                load_bias(n0, bias_nxt);
-            }
-            if (!(a.dbg & 8)) epilogue(cm0, cn0);
-            if (!more) break;
-            roll_bias();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    } else if constexpr (PIPE4) {
-        // ---- four stages of one 32-deep k-step: [stage][X sub-tiles BM/16 | W sub-tiles BN/16] x 1 KiB
-        constexpr int RX = BM / 16, RW = BN / 16, STAGE_BYTES = (RX + RW) * 1024;
-        constexpr int NQ = (RX + RW) / NWAVES, NQX = RX / NWAVES;          // DMA instructions per wave and k-step
-        static_assert(NQ * 2 <= 63, "vmcnt immediate");
-        unsigned soff[NQ];
-        auto set_sources4 = [&](int m0, int n0) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int s = w + NWAVES * i;
-                if (i < NQX) {
-                    int m = m0 + s * 16 + prow;
-                    m = m < a.M ? m : a.M - 1;
-                    unsigned base;
-                    if constexpr (AMODE == A_CONV) {
-                        const int FF = a.F * a.F, b = m / FF, yx = m - b * FF, y = yx / a.F, x = yx - y * a.F, P = a.F + 2;
-                        base = (unsigned)(((b * P + y) * P + x) * a.C);
-                    } else {
-                        base = (unsigned)m * (unsigned)a.K;
-                    }
-                    soff[i] = base + pk;
-                } else {
-                    soff[i] = (unsigned)(n0 + (s - RX) * 16 + prow) * (unsigned)a.K + pk;
-                }
-            }
-        };
-        auto issue = [&](int ks) {             // DMA of k-step ks into stage ks & 3
-            unsigned kx;
-            if constexpr (AMODE == A_CONV) {
-                const int per_tap = a.C / 32, tap = ks / per_tap, c0 = (ks - tap * per_tap) * 32, r = tap / 3, sx = tap - 3 * r;
-                kx = (unsigned)((r * (a.F + 2) + sx) * a.C + c0);
-            } else {
-                kx = (unsigned)ks * 32;
-            }
-            char* st = smem + (ks & 3) * STAGE_BYTES;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int s = w + NWAVES * i;
-                const bf16* g = i < NQX ? X + soff[i] + kx : W + soff[i] + (unsigned)ks * 32;
-                glds16(g, st + s * 1024 + lane * 16);
-            }
-        };
-        const int nks = a.K / 32;              // a multiple of 4 (host checks K % 128 == 0): the last step sits in stage 3
-        set_sources4((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-        issue(0); issue(1); issue(2);
-        for (;;) {
-            zero_acc();
-            for (int ks = 0; ks < nks; ++ks) {
-                // the DMA group of step ks has landed once at most the two younger groups are outstanding.  At ks == 0 the
-                // queue also holds the previous tile's epilogue stores behind the three prefetched groups: drain it.
-                if (ks == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (ks + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ) : "memory");
-                else if (ks + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();          // every wave's part of step ks is in LDS; stage (ks - 1) & 3 is free
-                if (ks + 3 < nks) issue(ks + 3);
-                const char* st = smem + (ks & 3) * STAGE_BYTES;
-                if (!(a.dbg & 4)) mfma_step(st + (wm * TM) * 1024 + fr, st + (RX + wn * TN) * 1024 + fr, 1024);
-            }
-            // stages 0..2 were last read in steps nks-4 .. nks-2, which every wave has finished (it passed the barrier of
-            // step nks-1): the next tile's first three steps can fly while this tile's epilogue runs
-            const int cm0 = m0, cn0 = n0;
-            vb += gridDim.x;
-            const bool more = vb < nwg;
-            if (more) {
-                tile_of(vb, m0, n0);
-                set_sources4((a.dbg & 1) ? 0 : m0, (a.dbg & 2) ? 0 : n0);
-                issue(0); issue(1); issue(2);
-                load_bias(n0, bias_nxt);
-            }
-            if (!(a.dbg & 8)) epilogue(cm0, cn0);
-            if (!more) break;
-            roll_bias();
+            stage_vec(m0, n0);           // the next tile's bias / rstd; the wait at the top of the loop covers them
         }
     } else {
         const int nk = a.K / BK;
@@ -986,11 +707,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                 tile_of(vb, m0, n0);
                 set_sources(m0, n0);
                 stage(0, smem);
-                load_bias(n0, bias_nxt);
             }
             epilogue(cm0, cn0);
             if (!more) break;
-            roll_bias();
+            stage_vec(m0, n0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }

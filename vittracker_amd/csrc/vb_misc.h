@@ -42,10 +42,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 //   map  (optional)  bf16 zero-bordered NHWC [B][F+2][F+2][C]: search rows only (forward_head's (B,C,F,F) view,
 //                    lib/models/ostrack/ostrack.py:126-129)         -> the head's implicit-GEMM input
 //   feat (optional)  f32 [B][Lx][C]: search rows only               -> stage API / tests
+//   xb + rstd (optional, together)  the LayerNorm folded into the next GEMM (vb_gemm.h): bf16 copy of the RAW row and its
+//                    1 / sqrt(var + eps) -- what the residual-writing GEMM epilogues + ln_finalize_kernel produce, for a
+//                    residual stream that arrived from outside (vt_blocks on caller-supplied tokens)
 template <int C>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ resid, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M, int L, int Lz, int F,
-                                                        bf16* __restrict__ xn, bf16* __restrict__ map, float* __restrict__ feat) {
+                                                        bf16* __restrict__ xn, bf16* __restrict__ map, float* __restrict__ feat,
+                                                        bf16* __restrict__ xb, float* __restrict__ rstd_out) {
     static_assert(C % 256 == 0, "C = 64 lanes x float4 x n");
     constexpr int NV = C / 256;
     const int lane = threadIdx.x & 63;
@@ -58,6 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         v[i] = ld4(p + i * 256 + lane * 4);
         s += hsum4(v[i]);
+        if (xb) *reinterpret_cast<bf16x4*>(xb + (size_t)row * C + i * 256 + lane * 4) = vbg::to_bf16x4(v[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -71,6 +76,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+    if (rstd_out) {
+        if (lane == 0) rstd_out[row] = rstd;
+        if (!xn && !map && !feat) return;
+    }
     const int f = row / L, t = row - f * L;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -86,6 +95,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (feat) st4(feat + ((size_t)f * (L - Lz) + tt) * C + c, y);
         }
     }
+}
+
+// Per-row rstd from the (sum, centred sum of squares) pairs the residual-writing GEMM epilogues leave per 64-column wave slice
+// (vb_gemm.h): Chan's pairwise update, exact mean first.  stats: [P][ld] float2, P = C / 64.  One thread per row.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restrict__ stats, int P, int ld, int M, float eps,
+                                                          float* __restrict__ rstd) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += stats[(size_t)p * ld + m].x;
+    const float inv_c = 1.0f / (64.0f * P), mean = s * inv_c;
+    float m2 = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const vbg::f2 v = stats[(size_t)p * ld + m];
+        const float d = v.x * (1.0f / 64.0f) - mean;
+        m2 += v.y + 64.0f * d * d;
+    }
+    rstd[m] = 1.0f / sqrtf(m2 * inv_c + eps);
 }
 
 // f32 (B, Lx, C) tokens -> the zero-bordered bf16 map (stage API: vt_head on caller-supplied features)

@@ -65,6 +65,11 @@ struct VbModel {
     // workspace
     Buf<bf16> xn, qk, vt, ao, hid, map0, map1, map2, map3, t4;
     Buf<float> resid;
+    // LayerNorm folded into qkv / fc1 (vb_gemm.h): xn then holds the RAW residual rows in bf16, written by the GEMM epilogues that
+    // produce them, rstd their 1 / sqrt(var + eps), stats the epilogues' per-slice (sum, M2) pairs [C / 64][max rows]
+    bool fold = true;
+    Buf<float> rstd;
+    Buf<vbg::f2> stats;
 };
 
 namespace {
@@ -148,11 +153,35 @@ hipError_t allow_lds(K kernel, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int run_layernorm(const float* resid, const float* g, const float* b, int B, hipStream_t st, bf16* xn, bf16* map, float* feat, const Err& E) {
+int run_layernorm(const float* resid, const float* g, const float* b, int B, hipStream_t st, bf16* xn, bf16* map, float* feat, const Err& E,
+                  bf16* xb = nullptr, float* rstd = nullptr) {
     const int M = B * L;
-    hipLaunchKernelGGL((vbm::layernorm_kernel<C>), dim3((M + 3) / 4), dim3(256), 0, st, resid, g, b, LN_EPS, M, L, LZ, F, xn, map, feat);
+    hipLaunchKernelGGL((vbm::layernorm_kernel<C>), dim3((M + 3) / 4), dim3(256), 0, st, resid, g, b, LN_EPS, M, L, LZ, F, xn, map, feat, xb,
+                       rstd);
     VB_HIP(hipGetLastError());
     return VT_OK;
+}
+
+constexpr int STAT_P = C / 64;       // (sum, M2) pairs per residual row: one per 64-column wave slice of the 256-wide GEMM tiles
+
+int run_finalize(const VbModel* m, size_t r0, int M, hipStream_t st, const Err& E) {
+    hipLaunchKernelGGL(vbm::ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, m->stats.p + r0, STAT_P, (int)(m->stats.n / STAT_P), M,
+                       LN_EPS, m->rstd.p + r0);
+    VB_HIP(hipGetLastError());
+    return VT_OK;
+}
+
+// LayerNorm(gamma, beta) folded into the Linear(W [N][K], b) that consumes it, in double (vb_gemm.h header):
+//     W'[n][k] = W[n][k] gamma[k] - mean_k(W[n][.] gamma[.]),   b'[n] = b[n] + sum_k W[n][k] beta[k]
+void fold_layernorm(std::vector<float>& w, std::vector<float>& b, const float* gamma, const float* beta, int N, int K) {
+    for (int n = 0; n < N; ++n) {
+        float* row = w.data() + (size_t)n * K;
+        double sb = 0.0, sg = 0.0;
+        for (int k = 0; k < K; ++k) { sb += (double)row[k] * beta[k]; sg += (double)row[k] * gamma[k]; }
+        const double mu = sg / K;
+        for (int k = 0; k < K; ++k) row[k] = (float)((double)row[k] * gamma[k] - mu);
+        b[n] = (float)((double)b[n] + sb);
+    }
 }
 
 }  // namespace
@@ -171,12 +200,14 @@ int create(const vt_config* cfg, VbModel** out, std::string* err) {
     m->depth = cfg->depth;
     m->maxB = cfg->max_batch;
     m->blk.resize(m->depth);
+    m->fold = env_int("VB_LN_FOLD", 1) != 0;
     const size_t B = (size_t)cfg->max_batch, M = B * L, P2 = (size_t)(F + 2) * (F + 2);
     hipError_t e = hipSuccess;
     auto A = [&](auto& buf, size_t n) { if (e == hipSuccess) e = buf.alloc(n); };
     A(m->xn, M * C); A(m->resid, M * C); A(m->qk, M * 2 * C); A(m->vt, M * C); A(m->ao, M * C); A(m->hid, M * HID);
     A(m->map0, B * P2 * C); A(m->map1, 3 * B * P2 * HEAD_CH[1]); A(m->map2, 3 * B * P2 * HEAD_CH[2]);
     A(m->map3, 3 * B * P2 * HEAD_CH[3]); A(m->t4, 3 * B * LX * HEAD_CH[4]);
+    A(m->rstd, M); A(m->stats, (size_t)STAT_P * M);
     // zero borders of the padded maps (kernels only ever write interiors)
     if (e == hipSuccess) e = hipMemset(m->map0.p, 0, m->map0.n * 2);
     if (e == hipSuccess) e = hipMemset(m->map1.p, 0, m->map1.n * 2);
@@ -210,6 +241,7 @@ void destroy(VbModel* m) {
     m->w5.release(); m->b5.release();
     m->xn.release(); m->qk.release(); m->vt.release(); m->ao.release(); m->hid.release(); m->map0.release();
     m->map1.release(); m->map2.release(); m->map3.release(); m->t4.release(); m->resid.release();
+    m->rstd.release(); m->stats.release();
     delete m;
 }
 
@@ -238,23 +270,32 @@ int load_weights(VbModel* m, const TensorMap& tm, std::string* err) {
         const std::string pre = bb + "blocks." + std::to_string(i) + ".";
         struct V { const char* name; Buf<float>* dst; int n; };
         const V vecs[] = {{"norm1.weight", &b.ln1g, C}, {"norm1.bias", &b.ln1b, C}, {"norm2.weight", &b.ln2g, C}, {"norm2.bias", &b.ln2b, C},
-                          {"attn.proj.bias", &b.bproj, C}, {"mlp.fc1.bias", &b.b1, HID}, {"mlp.fc2.bias", &b.b2, C}};
+                          {"attn.proj.bias", &b.bproj, C}, {"mlp.fc2.bias", &b.b2, C}};
         for (const V& v : vecs) {
             if ((rc = need(tm, pre + v.name, v.n, &p, E))) return rc;
             if ((rc = upload_f32(*v.dst, p, v.n, E))) return rc;
         }
+        const float *g1, *be1, *g2, *be2;
+        if ((rc = need(tm, pre + "norm1.weight", C, &g1, E)) || (rc = need(tm, pre + "norm1.bias", C, &be1, E))) return rc;
+        if ((rc = need(tm, pre + "norm2.weight", C, &g2, E)) || (rc = need(tm, pre + "norm2.bias", C, &be2, E))) return rc;
         if ((rc = need(tm, pre + "attn.qkv.weight", (int64_t)3 * C * C, &p, E))) return rc;
         std::vector<float> w(p, p + (size_t)3 * C * C);
-        for (size_t k = 0; k < (size_t)C * C; ++k) w[k] *= scale;
-        if ((rc = upload_bf16(b.wqkv, w, E))) return rc;
         if ((rc = need(tm, pre + "attn.qkv.bias", 3 * C, &p, E))) return rc;
         std::vector<float> bq(p, p + 3 * C);
+        if (m->fold) fold_layernorm(w, bq, g1, be1, 3 * C, C);
+        for (size_t k = 0; k < (size_t)C * C; ++k) w[k] *= scale;
         for (int k = 0; k < C; ++k) bq[k] *= scale;
+        if ((rc = upload_bf16(b.wqkv, w, E))) return rc;
         if ((rc = upload_f32(b.bqkv, bq.data(), bq.size(), E))) return rc;
         if ((rc = need(tm, pre + "attn.proj.weight", (int64_t)C * C, &p, E))) return rc;
         if ((rc = upload_bf16(b.wproj, std::vector<float>(p, p + (size_t)C * C), E))) return rc;
         if ((rc = need(tm, pre + "mlp.fc1.weight", (int64_t)HID * C, &p, E))) return rc;
-        if ((rc = upload_bf16(b.w1, std::vector<float>(p, p + (size_t)HID * C), E))) return rc;
+        std::vector<float> w1(p, p + (size_t)HID * C);
+        if ((rc = need(tm, pre + "mlp.fc1.bias", HID, &p, E))) return rc;
+        std::vector<float> b1(p, p + HID);
+        if (m->fold) fold_layernorm(w1, b1, g2, be2, HID, C);
+        if ((rc = upload_bf16(b.w1, w1, E))) return rc;
+        if ((rc = upload_f32(b.b1, b1.data(), b1.size(), E))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", (int64_t)HID * C, &p, E))) return rc;
         if ((rc = upload_bf16(b.w2, std::vector<float>(p, p + (size_t)HID * C), E))) return rc;
     }
@@ -328,15 +369,18 @@ int stem(VbModel* m, const float* z, const float* x, int B, hipStream_t st, floa
     const size_t r0 = (sl ? sl->f0 : 0) * L;          // first token row of the slice
     const int cus = sl ? sl->cus : 0;
     bf16* const xn = m->xn.p + r0 * C;
+    bf16* const patches = (m->fold ? m->ao.p : m->xn.p) + r0 * C;     // folded: xn receives the tokens' bf16 copy from the GEMM epilogue
     float* const resid = m->resid.p + r0 * C;
     const size_t items = (size_t)M * 96;
-    hipLaunchKernelGGL(vbm::patchify_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 16384)), dim3(256), 0, st, z, x, xn, B,
-                       128, 256);
+    hipLaunchKernelGGL(vbm::patchify_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 16384)), dim3(256), 0, st, z, x, patches,
+                       B, 128, 256);
     VB_HIP(hipGetLastError());
     vbg::Args a{};
-    a.X = xn; a.W = m->wpatch.p; a.bias = m->bpatch.p; a.resid = resid; a.pos = m->pos.p;
+    a.X = patches; a.W = m->wpatch.p; a.bias = m->bpatch.p; a.resid = resid; a.pos = m->pos.p;
     a.M = M; a.N = C; a.K = PATCH_K; a.L = L;
+    if (m->fold) { a.xb = xn; a.stats = m->stats.p + r0; a.ldstats = (int)(m->stats.n / STAT_P); }
     if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_PATCH>(a, 1, st, E, cus))) return rc;
+    if (m->fold && (rc = run_finalize(m, r0, M, st, E))) return rc;
     if (tokens_out) VB_HIP(hipMemcpyAsync(tokens_out, resid, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
     return VT_OK;
 }
@@ -359,30 +403,42 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
     if (nblocks < 0 || nblocks > m->depth) nblocks = m->depth;
     if (tokens_in && tokens_in != resid)
         VB_HIP(hipMemcpyAsync(resid, tokens_in, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
+    const bool fold = m->fold;
+    float* const rstd = fold ? m->rstd.p + r0 : nullptr;
+    vbg::f2* const stats = m->stats.p + r0;
+    const int ldstats = (int)(m->stats.n / STAT_P);
+    // folded LayerNorms: a residual stream from outside has no bf16 copy / rstd yet (vb::stem leaves both behind its GEMM)
+    if (fold && tokens_in && nblocks > 0 && (rc = run_layernorm(resid, nullptr, nullptr, B, st, nullptr, nullptr, nullptr, E, xn, rstd))) return rc;
     for (int i = 0; i < nblocks; ++i) {
         const BlockW& b = m->blk[i];
-        if ((rc = run_layernorm(resid, b.ln1g.p, b.ln1b.p, B, st, xn, nullptr, nullptr, E))) return rc;
+        if (!fold && (rc = run_layernorm(resid, b.ln1g.p, b.ln1b.p, B, st, xn, nullptr, nullptr, E))) return rc;
         vbg::Args a{};
+        a.rstd = rstd;
         a.X = xn; a.W = b.wqkv.p; a.bias = b.bqkv.p; a.out = qk;          // q | k: rows 0 .. 2C of W_qkv
         a.M = M; a.N = 2 * C; a.K = C; a.ldo = 2 * C; a.rb = 4;    // 4 tile rows x 8 columns per XCD: measured 4 % faster than row-major
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_BF16>(a, 1, st, E, cus))) return rc;
         vbg::Args v{};
         v.X = xn; v.W = b.wqkv.p + (size_t)2 * C * C; v.bias = b.bqkv.p + 2 * C; v.vt = vt;   // v: rows 2C .. 3C, stored transposed
-        v.M = M; v.N = C; v.K = C; v.L = L;
+        v.M = M; v.N = C; v.K = C; v.L = L; v.rstd = rstd;
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_VT>(v, 1, st, E, cus))) return rc;
         constexpr int attn_lds = vba::Geo<L, HD>::LDS_BYTES;
         hipLaunchKernelGGL((vba::attn_kernel<L, HD>), dim3(B * HEADS), dim3(256), attn_lds, st, qk, vt, ao, HEADS);
         VB_HIP(hipGetLastError());
         vbg::Args p{};
         p.X = ao; p.W = b.wproj.p; p.bias = b.bproj.p; p.resid = resid; p.M = M; p.N = C; p.K = C;
+        if (fold) { p.xb = xn; p.stats = stats; p.ldstats = ldstats; }
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(p, 1, st, E, cus))) return rc;
-        if ((rc = run_layernorm(resid, b.ln2g.p, b.ln2b.p, B, st, xn, nullptr, nullptr, E))) return rc;
+        if (fold ? (rc = run_finalize(m, r0, M, st, E)) : (rc = run_layernorm(resid, b.ln2g.p, b.ln2b.p, B, st, xn, nullptr, nullptr, E))) return rc;
         vbg::Args f1{};
+        f1.rstd = rstd;
         f1.X = xn; f1.W = b.w1.p; f1.bias = b.b1.p; f1.out = hid; f1.M = M; f1.N = HID; f1.K = C; f1.ldo = HID; f1.rb = 4;
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_GELU>(f1, 1, st, E, cus))) return rc;
         vbg::Args f2{};
         f2.X = hid; f2.W = b.w2.p; f2.bias = b.b2.p; f2.resid = resid; f2.M = M; f2.N = C; f2.K = HID;
+        const bool feeds_ln = fold && i + 1 < nblocks;            // the final norm reads the f32 stream itself
+        if (feeds_ln) { f2.xb = xn; f2.stats = stats; f2.ldstats = ldstats; }
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(f2, 1, st, E, cus))) return rc;
+        if (feeds_ln && (rc = run_finalize(m, r0, M, st, E))) return rc;
     }
     if (resid_out) VB_HIP(hipMemcpyAsync(resid_out, resid, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
     return run_layernorm(resid, m->ng.p, m->nb.p, B, st, nullptr, map0, feat_out, E);
