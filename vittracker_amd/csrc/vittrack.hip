@@ -112,7 +112,8 @@ struct vt_model {
     int stem_fuse = 1;     // stem_a: one workgroup = band k of both crops (G128: 4 instead of 5 workgroups per frame)
     int stem_bf3 = 1;      // VT_STEM_BF3: layer 3 of stem_fused as exact three-piece bf16 products (fp32 build); 0 = fp32 MFMAs
     int blocks_bf3_g256 = 1;   // the same switch at G256 (MLP only, weights from L2)
-    int blocks_bf3 = 1;    // VT_BLOCKS_BF3: the G128 frame form's MLP as exact three-piece bf16 products (0 = fp32 MFMA)
+    int blocks_bf3 = 2;    // VT_BLOCKS_BF3: the G128 frame form's contractions as exact three-piece bf16 products: 2 = all of them
+                           // (A3: attention + proj too), 1 = qkv + MLP, 0 = fp32 MFMAs
     int blocks_bal = 1;    // G128 block kernel: balanced 4 owner + 4 guest waves (1) or one wave per tile (0)
     int blocks_wlds = 1;   // G128 block kernel: weights staged through LDS (1) or read from L2 per wave (0)
     int form_batch = 0;    // vt_set_form_batch: kernel forms are chosen as for a batch of this size (0: by the batch of each call)
@@ -249,10 +250,11 @@ void pack_k48_image3(const float* img1, int ntiles, uint16_t* dst) {
     }
 }
 
-void pack_mlp_images3(const float* img1, const float* img2, const float* imgqkv, uint16_t* dst) {
+void pack_mlp_images3(const float* img1, const float* img2, const float* imgqkv, const float* imgproj, uint16_t* dst) {
     constexpr int NC = vtb::NC, NH = vtb::NH;
     uint16_t pcs[3];
     pack_k48_image3(imgqkv, 9, dst + (size_t)(vtb::W3_FC1_TILES + vtb::W3_FC2_TILES) * 512);
+    pack_k48_image3(imgproj, NC, dst + (size_t)(vtb::W3_FC1_TILES + vtb::W3_FC2_TILES + vtb::W3_QKV_TILES) * 512);      // A3
     for (int ot = 0; ot < NH; ++ot) {           // fc1: [ot][ pair 0: piece x lane x 8 | chunk 2: piece x lane x 4 ]
         uint16_t* o = dst + (size_t)ot * vtb::W3_FC1_OT16 * 8;
         for (int l = 0; l < 64; ++l) {
@@ -484,19 +486,23 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
 
 // dynamic LDS of blocks_kernel<NT, ., ., WLDS, BAL> at a given depth: K/V images, weight staging buffers,
 // the small parameters (LayerNorm vectors + biases of every block) and the guests' exchange area
-size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth, bool BF3 = false) {
+size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth, bool BF3 = false, bool A3 = false) {
+    if (A3)     // K / V^T as pieces (vt_blocks.h: KV_UNITS); of the guests' areas only Dg and the counter keep room of their own
+        return ((size_t)NT * vtb::W3_FC1_OT16 + (size_t)vtb::NC * ((NT / 2) * 3 * 64 + (NT & 1) * 3 * 32) +
+                (size_t)(vtb::W3_FC1_TILES + vtb::WBUF_TILES) * 64) * sizeof(f4) +
+               (size_t)vtb::small_floats(depth) * sizeof(float) + (size_t)vtb::NC * 64 * sizeof(f4) + 64;
     return ((size_t)2 * NT * vtb::NC + (WLDS ? (BF3 ? vtb::W3_FC1_TILES : vtb::WBUF_TILES) + vtb::WBUF_TILES : 0)) * 64 * sizeof(f4) +
            (size_t)vtb::small_floats(depth) * sizeof(float) +
            (BAL ? (size_t)(vtb::NC + 4 * vtb::NC + vtb::NC) * 64 * sizeof(f4) + 4 * 2 * 64 * sizeof(float) + 64 : 0);
 }
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false>
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false, bool A3 = false>
 int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode) {
     if (zcache_mode != 0 && !ZC)
         return fail(VT_ERR_STATE, "the template cache needs the default block kernel (VT_BLOCKS_BAL = 1)");
-    const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth, BF3);
-    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC, BF3>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
+    const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth, BF3, A3);
+    hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC, BF3, A3>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
                        resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode, m->blocks3.p);
     HIP_TRY(hipGetLastError());
     return VT_OK;
@@ -548,6 +554,9 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     switch (m->L / 16) {
         case 5:
 #ifndef VT_F16
+            if (m->blocks_bal && m->blocks_bf3 >= 2)
+                return zc ? launch_blocks<5, 8, 1, true, true, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                          : launch_blocks<5, 8, 1, true, true, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
             if (m->blocks_bal && m->blocks_bf3)
                 return zc ? launch_blocks<5, 8, 1, true, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                           : launch_blocks<5, 8, 1, true, true, false, true>(m, st, tokens, B, nblocks, feat, resid, zc);
@@ -946,8 +955,9 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
     m->blocks_wlds = env_int("VT_BLOCKS_WLDS", 1);
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
-    m->blocks_bf3 = env_int("VT_BLOCKS_BF3", 1);
+    m->blocks_bf3 = env_int("VT_BLOCKS_BF3", 2);
     m->blocks_bf3_g256 = m->blocks_bf3;
+    if (m->blocks_bf3 >= 2 && blocks_lds_bytes(5, true, true, cfg->depth, true, true) > LDS_PER_CU) m->blocks_bf3 = 1;
     // the BF3 form's staging buffers are 18 KiB larger: beyond depth 8 its small parameters no longer fit beside them -> fp32 form
     if (blocks_lds_bytes(5, true, true, cfg->depth, true) > LDS_PER_CU) m->blocks_bf3 = 0;
     m->stem_fused = env_int("VT_STEM_FUSED", -1);
@@ -1004,6 +1014,12 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess && m->blocks_bf3)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth, true));
+        if (e == hipSuccess && m->blocks_bf3 >= 2)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth, true, true));
+        if (e == hipSuccess && m->blocks_bf3 >= 2)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<5, 8, 1, true, true, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(5, true, true, cfg->depth, true, true));
 #endif
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true>),
@@ -1186,7 +1202,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
-        pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, dst + vtb::O_WQKV, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
+        pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, dst + vtb::O_WQKV, dst + vtb::O_WPROJ, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
     }
     {
         float* dst = bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE;

@@ -53,13 +53,21 @@ static_assert(BLOCK_STRIDE % 4 == 0 && O_WQKV % 4 == 0 && O_W1 % 4 == 0 && O_W2 
 //   fc2 (K = 192 = 6 chunk pairs):               [out tile 3][pair 6][piece 3][64 lanes x 16 B]                                     = 54 KiB
 //   qkv (K = 48; LN1 folded), fc1's layout:      [out tile 9: q 0-2, k 3-5, v 6-8][ pair 0 | chunk 2 ]                              = 40.5 KiB
 // (v: the operands swap roles -- tokens as rows, so V lands transposed -- which the 16 x 16 x 32 instruction's identical A / B
-// register layouts make free: the same image serves.)  proj (9 KiB) and the attention products stay on fp32 MFMAs: K / V^T as
-// pieces would need 15 KiB more LDS than the CU has left.
+// register layouts make free: the same image serves.)  BF3 alone leaves proj (9 KiB) and the attention products on fp32 MFMAs.
+// A3 (round 5, G128 frame form): those too -- K, V^T and the guests' q are PUBLISHED as pieces (split once by the wave that computes
+// them), S^T = K q^T, O^T = V^T P^T and proj run as six-term products; nothing in the kernel issues an fp32 MFMA any more.  LDS:
+//   K pieces   [key tile NT][ pair 0: piece 3 x 64 x 16 B | chunk 2: piece 3 x 64 x 8 B ]     (a key tile = one fc1-layout "output tile")
+//   V^T pieces [feature tile NC][ key-chunk pair NT / 2: piece 3 x 64 x 16 B | odd last chunk: piece 3 x 64 x 8 B ]
+//   proj       fc1's layout, 3 output tiles (13.5 KiB, in buffer B)
+// = 45 instead of 30 KiB for K / V^T; the room comes from the guests' exchange areas, which move into space that is idle in
+// their phase: q pieces / attention partials / softmax statistics behind proj's image in buffer B (free until fc2 is staged
+// after the attention barrier), the fc2 partial sums behind the next block's qkv image in buffer A (free until fc1 is staged).
 constexpr int W3_FC1_TILES = NH * 3 + NH * 3 / 2;     // KiB tiles (the LDS-DMA unit)
 constexpr int W3_FC1_OT16 = 3 * 64 + 3 * 32;          // 16-byte units per output tile (288)
 constexpr int W3_FC2_TILES = NC * (NH / 2) * 3;
 constexpr int W3_QKV_TILES = (9 * W3_FC1_OT16 + 63) / 64;                // qkv (K = 48, 9 output tiles) in fc1's layout: 40.5 KiB, staged as 41
-constexpr int BLOCK3_STRIDE = (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 256;      // floats: [fc1 | fc2 | qkv]
+constexpr int W3_PROJ_TILES = (NC * W3_FC1_OT16 + 63) / 64;               // proj (K = 48, 3 output tiles) in fc1's layout: 13.5 KiB, staged as 14 (A3)
+constexpr int BLOCK3_STRIDE = (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES + W3_PROJ_TILES) * 256;      // floats: [fc1 | fc2 | qkv | proj]
 static_assert(W3_FC1_TILES == 54 && W3_FC2_TILES == 54 && NH * W3_FC1_OT16 == W3_FC1_TILES * 64, "three-piece MLP images");
 
 // The small parameters of a block (LayerNorm gamma / beta and the four bias vectors, 624 floats) are
@@ -105,9 +113,10 @@ __device__ __forceinline__ void wburst(f4 (&a)[N], const float* __restrict__ bas
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Tell the scheduler to issue `n` rounds of {1 MFMA, `valu` VALU/transcendental ops}: a wave can
-// issue ~6 independent vector ops in the 32-cycle shadow of each v_mfma_f32_16x16x4_f32, which is
-// how GELU of one hidden group hides behind the MFMAs of the next.
+// Tell the scheduler to issue `n` rounds of {1 MFMA, `valu` VALU/transcendental ops} (the fp32-MFMA forms' MLP: GELU of one hidden
+// group written between the MFMAs of the next).  What that buys is instruction ORDER, not overlap: nothing issues on a SIMD while
+// one of its waves executes v_mfma_f32_16x16x4_f32 (tools/src/probe_coexec.hip, NOTES R4-1); beside a bf16 MFMA about two plain
+// vector instructions per MFMA do.
 template <int N, int VALU_PER_MFMA>
 __device__ __forceinline__ void interleave_mfma_valu() {
 #pragma unroll
@@ -231,7 +240,7 @@ __device__ __forceinline__ void gemm_stage(OpA opa, OpS ops, f4 (&acc)[N]) {
 //     fc2         K-split: guest g contracts its own hidden tiles -> partial in LDS; summed (36)
 // Each SIMD then issues ~708 instead of 1104 MFMAs per block, and has a second instruction stream that
 // fills the owner's waits (f32 MFMA and VALU issue add up even across waves: tools/src/probe_overlap.hip).
-template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false>   // ZC: template-cache variant (config 5); BF3: MLP on the bf16 pipe
+template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false, bool A3 = false>   // ZC: template-cache variant (config 5); BF3: qkv + MLP on the bf16 pipe; A3: attention + proj too
 __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_kernel(const float* __restrict__ tokens,   // (B, L, C)
                                                          const float* __restrict__ params,   // packed, see O_*
                                                          float* __restrict__ feat,           // (B, Lx, C)
@@ -250,6 +259,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     constexpr bool BF3L = BF3 && WLDS, BF3G = BF3 && !WLDS;
     static_assert(!BF3L || (BAL && 2 * NT * NC >= W3_FC2_TILES - WBUF_TILES), "BF3 with staging: written for the balanced frame form; fc2's third output tile is staged in the K / V area");
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
+    static_assert(!A3 || BF3L, "A3: written for the staged three-piece form");
+    // A3: 16-byte units per key tile of the K pieces / per feature tile of the V^T pieces
+    constexpr int KP_T16 = W3_FC1_OT16, VP_PAIRS = NT / 2, VP_T16 = VP_PAIRS * 3 * 64 + (NT & 1) * 3 * 32;
+    constexpr int KV_UNITS = A3 ? NT * KP_T16 + NC * VP_T16 : 2 * NT * NC * 64;
     constexpr int L = NT * 16;
     constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
     constexpr int GT = NT - 1;                             // BAL: the guests' tile
@@ -259,16 +272,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     // the K and V^T images as STORED operands (f16 build: h4, half the bytes of the same area; written once per block, read by every wave)
     opnd* const Ko = reinterpret_cast<opnd*>(Kimg);
     opnd* const Vo = reinterpret_cast<opnd*>(Vimg);
-    f4* Wa = Vimg + NT * NC * 64;                          // WLDS: [36][64] staging buffer A
+    f4* Wa = Kimg + KV_UNITS;                              // WLDS: [36][64] staging buffer A
     constexpr int WA_TILES = BF3L ? W3_FC1_TILES : WBUF_TILES;      // BF3: fc1's three-piece image is 54 KiB
     f4* Wb = Wa + WA_TILES * 64;                           // WLDS: [36][64] staging buffer B (BF3: fc2's output tiles 0 and 1; tile 2 goes to the K / V area, free during the MLP)
     float* Sp = reinterpret_cast<float*>(WLDS ? Wb + WBUF_TILES * 64 : Wa);   // small parameters, small_floats(depth)
-    // BAL: guest exchange areas
-    f4* Qg = reinterpret_cast<f4*>(Sp + small_floats(depth_total));   // [NC][64]      q of the guest tile
-    f4* Pg = Qg + NC * 64;                                            // [4][NC][64]   attention / fc2 partials
-    f4* Dg = Pg + 4 * NC * 64;                                        // [NC][64]      proj output tiles
-    float* Mg = reinterpret_cast<float*>(Dg + NC * 64);               // [4][2][64]    partial softmax max / sum
-    int* gflag = reinterpret_cast<int*>(Mg + 4 * 2 * 64);             // guests' rendezvous counter
+    // BAL: guest exchange areas.  A3: only Dg and the counter keep room of their own (header comment)
+    f4* const Gx = reinterpret_cast<f4*>(Sp + small_floats(depth_total));
+    f4* Qg = A3 ? Wb + W3_PROJ_TILES * 64 : Gx;                       // [NC][64]      q of the guest tile (A3: as pieces, KP_T16 units)
+    f4* Pg = Qg + (A3 ? KP_T16 : NC * 64);                            // [4][NC][64]   attention / fc2 partials
+    f4* Dg = A3 ? Gx : Pg + 4 * NC * 64;                              // [NC][64]      proj output tiles
+    float* Mg = reinterpret_cast<float*>(A3 ? Pg + 4 * NC * 64 : Dg + NC * 64);              // [4][2][64]    partial softmax max / sum
+    int* gflag = A3 ? reinterpret_cast<int*>(Dg + NC * 64) : reinterpret_cast<int*>(Mg + 4 * 2 * 64);   // guests' rendezvous counter
+    f4* Pg2 = A3 ? Wa + W3_QKV_TILES * 64 : Pg;                       // [4][NC][64]   fc2 partial sums
+    static_assert(!A3 || (W3_PROJ_TILES * 64 + KP_T16 + 4 * NC * 64 + 4 * 2 * 64 / 4 <= WBUF_TILES * 64 && W3_QKV_TILES * 64 + 4 * NC * 64 <= W3_FC1_TILES * 64),
+                  "A3: the exchange areas fit behind proj's / qkv's image");
 
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -402,7 +419,51 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
             return accA + accB;
         };
-        if constexpr (BF3L) {
+        // ---- A3: K / V^T / q / proj as three-piece operands (layouts: header comment)
+        const auto Kp3 = A3 ? lds_lane_base<u32x4>(Kimg, 16u * lane3) : nullptr;                                   // key tile J, pair-0 piece pc: [J * KP_T16 + pc * 64]
+        const auto Kp3h = A3 ? lds_lane_base<u32x2>(Kimg, 192u * 16u + 8u * lane3) : nullptr;                      // chunk-2 piece: [J * KP_T16 * 2 + pc * 64]
+        const auto Vp3 = A3 ? lds_lane_base<u32x4>(Kimg + NT * KP_T16, 16u * lane3) : nullptr;                     // feature tile t, pair p: [t * VP_T16 + (p * 3 + pc) * 64]
+        const auto Vp3h = A3 ? lds_lane_base<u32x2>(Kimg + NT * KP_T16, VP_PAIRS * 3 * 64 * 16u + 8u * lane3) : nullptr;   // odd last chunk: [t * VP_T16 * 2 + pc * 64]
+        auto k_load3 = [&](int J, u32x4 (&a0)[3], u32x2 (&a2)[3]) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a0[pc] = Kp3[J * KP_T16 + pc * 64];
+                a2[pc] = Kp3h[J * KP_T16 * 2 + pc * 64];
+            }
+        };
+        auto wp_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {       // proj pieces of output tile t (buffer B, fc1's layout)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a0[pc] = Wb3[t * W3_FC1_OT16 + pc * 64];
+                a2[pc] = reinterpret_cast<const u32x2*>(Wb)[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+            }
+        };
+        auto store_k3 = [&](f4* dst_tile, const f4 (&kr)[NC]) {            // a token tile's k (or the guests' q) as pieces: one "output tile" of fc1's layout
+            u32x4 kb[3];
+            u32x2 kc[3];
+            split_h3(kr, kb, kc);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                reinterpret_cast<u32x4*>(dst_tile)[pc * 64 + lane3] = kb[pc];
+                reinterpret_cast<u32x2*>(dst_tile + 192)[pc * 64 + lane3] = kc[pc];
+            }
+        };
+        // unit offset (u32x2) of key chunk J's half inside feature tile t's V^T pieces, piece pc at + pc * 128 (pair) / + pc * 64 (odd chunk)
+        auto store_v3 = [&](int T, int ot, f4 r) {                          // V^T chunk T (this wave's token tile) of feature tile ot
+            u32x2 pv[3];
+            vt3::split3(r, pv[0], pv[1], pv[2]);
+            u32x2* base = reinterpret_cast<u32x2*>(Kimg + NT * KP_T16 + ot * VP_T16);
+            if ((NT & 1) && T == NT - 1) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) base[VP_PAIRS * 3 * 64 * 2 + pc * 64 + lane3] = pv[pc];
+            } else {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) base[(((T >> 1) * 3 + pc) * 64 + lane3) * 2 + (T & 1)] = pv[pc];
+            }
+        };
+        if constexpr (A3) {
+            stage_tiles(Wb, P3 + (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 256, W3_PROJ_TILES, w, NW, lane, blk == 0);
+        } else if constexpr (BF3L) {
             stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane, blk == 0);
         } else if constexpr (WLDS) stage_img(Wb, O_WPROJ, NC * NC, blk);   // proj: free since the last barrier
 
@@ -421,8 +482,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
                     qr[i][ot] = zc[ot * 64];
-                    Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
-                    Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
+                    if constexpr (A3) {
+                        store_v3(T, ot, zc[(2 * NC + ot) * 64]);
+                    } else {
+                        Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
+                        Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
+                    }
+                }
+                if constexpr (A3) {
+                    f4 kr[NC];
+#pragma unroll
+                    for (int ot = 0; ot < NC; ++ot) kr[ot] = zc[(NC + ot) * 64];
+                    store_k3(Kimg + T * KP_T16, kr);
                 }
             } else if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile) {
                 f4 h[NC];
@@ -452,6 +523,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     // lgkmcnt(0) -- for the prefetch just issued: one exposed LDS round trip per tile (round 4)
                     auto bias_q = [&](int t) { return t < 2 * NC ? ld4(S + S_BQKV + 16 * t + 4 * q) : splat4(S[S_BQKV + 2 * C + 16 * (t % NC) + tok]); };
                     f4 bias[2];
+                    f4 kr[NC];           // A3: k of this token tile, published as pieces once all three feature chunks are there
                     wq_load3(0, a0[0], a2[0]);
                     bias[0] = bias_q(0);
 #pragma unroll
@@ -466,6 +538,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         if (t < 2 * NC) r = tile48(std::false_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
                         else r = tile48(std::true_type{}, a0[t & 1], a2[t & 1], hb, hc, bias[t & 1]);
                         if (t < NC) qr[i][ot] = r;
+                        else if constexpr (A3) {
+                            if (t < 2 * NC) {
+                                kr[ot] = r;
+                                if (ot == NC - 1) store_k3(Kimg + T * KP_T16, kr);
+                            } else store_v3(T, ot, r);
+                        }
                         else if (t < 2 * NC) Ko[(T * NC + ot) * 64 + lane] = to_opnd(r);
                         else Vo[(ot * NT + T) * 64 + lane] = to_opnd(r);
                         if (z_tile && zcache_mode == 1) zc[t * 64] = r;
@@ -528,10 +606,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < NC; ++j) r[j] = tile48(std::false_type{}, a0[j], a2[j], hb, hc, bias[j]);
+                    if constexpr (A3) {
+                        store_k3(g == 0 ? Qg : Kimg + GT * KP_T16, r);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) {
-                        if (g == 0) Qg[j * 64 + lane] = r[j];
-                        else Ko[(GT * NC + j) * 64 + lane] = to_opnd(r[j]);
+                        for (int j = 0; j < NC; ++j) {
+                            if (g == 0) Qg[j * 64 + lane] = r[j];
+                            else Ko[(GT * NC + j) * 64 + lane] = to_opnd(r[j]);
+                        }
                     }
                 } else {
                     f4 bias[NC];
@@ -541,7 +623,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                     for (int j = 0; j < NC; ++j) r[j] = tile48(std::true_type{}, a0[j], a2[j], hb, hc, bias[j]);
 #pragma unroll
-                    for (int j = 0; j < NC; ++j) Vo[(j * NT + GT) * 64 + lane] = to_opnd(r[j]);
+                    for (int j = 0; j < NC; ++j) {
+                        if constexpr (A3) store_v3(GT, j, r[j]);
+                        else Vo[(j * NT + GT) * 64 + lane] = to_opnd(r[j]);
+                    }
                 }
             } else if (VT_BLK_GUESTS && w >= NOWN && g < 3) {      // guest 0: q, guest 1: k, guest 2: v of the guest tile
                 f4 h[NC];
@@ -589,7 +674,109 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int T = w + NW * i;
-            if (VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+            if (A3 && VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
+                // A3: the same attention + proj as six-term bf16 products.  q is split here (it stayed fp32 across the barrier: 12 instead
+                // of 18 registers), the scores' exponentials are split as they are produced, o after its normalisation.
+                constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+                u32x4 qb[3];
+                u32x2 qc[3];
+                split_h3(qr[i], qb, qc);
+                f4 s[NT];
+                float m0 = -3.0e38f, m1 = -3.0e38f;
+                {
+                    u32x4 a0[2][3];
+                    u32x2 a2[2][3];
+                    k_load3(0, a0[0], a2[0]);
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) {       // S^T tiles: rows = keys (A = K pieces), cols = queries (B = q pieces)
+                        if (J + 1 < NT) k_load3(J + 1, a0[(J + 1) & 1], a2[(J + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        s[J] = tile48(std::false_type{}, a0[J & 1], a2[J & 1], qb, qc, splat4(0.f));
+                        m0 = fmaxf(fmaxf(m0, s[J].x), s[J].y);
+                        m1 = fmaxf(fmaxf(m1, s[J].z), s[J].w);
+                    }
+                }
+                fstamp();
+                const float m = quad_max(fmaxf(m0, m1));
+                const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m * SCALE_LOG2E, -m * SCALE_LOG2E};
+                f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+                u32x4 pb[VP_PAIRS > 0 ? VP_PAIRS : 1][3];      // P^T as pieces: key-chunk pairs ...
+                u32x2 po[3], plo[3];                            // ... the odd last chunk; a pair's first chunk
+                // one key-chunk pair's V^T pieces (three feature tiles: 36 registers) at a time; the first pair's are requested in front
+                // of the exponentials
+                u32x4 v[NC][3];
+                auto v_load3 = [&](int pp) {
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) v[t][pc] = Vp3[t * VP_T16 + (pp * 3 + pc) * 64];
+                };
+                if (VP_PAIRS > 0) v_load3(0);
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
+                    const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
+                    const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                    const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                    d0 += ea;
+                    d1 += ec;
+                    u32x2 pj[3];
+                    vt3::split3(f4{ea.x, ea.y, ec.x, ec.y}, pj[0], pj[1], pj[2]);
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        if ((NT & 1) && J == NT - 1) po[pc] = pj[pc];
+                        else if (J & 1) pb[J >> 1][pc] = u32x4{plo[pc].x, plo[pc].y, pj[pc].x, pj[pc].y};
+                        else plo[pc] = pj[pc];
+                    }
+                }
+                const f2 dd = d0 + d1;
+                const float rden = __builtin_amdgcn_rcpf(quad_sum(dd.x + dd.y));     // v_rcp_f32: 1 ulp
+                fstamp();
+                f4 oA[NC], oB[NC];
+#pragma unroll
+                for (int t = 0; t < NC; ++t) oA[t] = oB[t] = splat4(0.f);
+                u32x2 vh[NC][3];
+                if (NT & 1) {
+#pragma unroll
+                    for (int t = 0; t < NC; ++t)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) vh[t][pc] = Vp3h[t * VP_T16 * 2 + pc * 64];
+                }
+#pragma unroll
+                for (int pp = 0; pp < VP_PAIRS; ++pp) {        // O^T = V^T P^T: 3 feature-tile chains share B = a pair's P pieces
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+#pragma unroll
+                        for (int t = 0; t < NC; ++t) oA[t] = vt3::mma(v[t][TW[e]], pb[pp][TX[e]], oA[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (pp + 1 < VP_PAIRS) v_load3(pp + 1);
+                }
+                // proj's pieces of the first output tile, requested under the last MFMAs of P.V
+                u32x4 wa0[2][3];
+                u32x2 wa2[2][3];
+                wp_load3(0, wa0[0], wa2[0]);
+                if (NT & 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)
+#pragma unroll
+                        for (int t = 0; t < NC; ++t) oB[t] = vt3::mma16(vh[t][TW[e]], po[TX[e]], oB[t]);
+                }
+                f4 o[NC];
+#pragma unroll
+                for (int t = 0; t < NC; ++t) o[t] = (oA[t] + oB[t]) * splat4(rden);
+                fstamp();
+                u32x4 ob[3];
+                u32x2 oc[3];
+                split_h3(o, ob, oc);
+#pragma unroll
+                for (int ot = 0; ot < NC; ++ot) {
+                    if (ot + 1 < NC) wp_load3(ot + 1, wa0[(ot + 1) & 1], wa2[(ot + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    x[i][ot] = tile48(std::false_type{}, wa0[ot & 1], wa2[ot & 1], ob, oc, x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q));
+                }
+            } else if (!A3 && VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                 // softmax((q k^T) * scale) (attn.py:40-41) as exp2(raw * (scale log2 e) - max_raw * (scale log2 e)): the scale, the
                 // subtraction and exp's own log2 e factor become ONE packed fma per two scores, the row maximum runs on v_max3 and the
                 // row sum on packed adds -- 10 instead of 22 VALU instructions per score tile (scale > 0: the raw maximum is the maximum)
@@ -709,8 +896,83 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     Mg[(g * 2 + 0) * 64 + lane] = m;
                     Mg[(g * 2 + 1) * 64 + lane] = den;
                 };
-                if (g == 3) attn_part(std::integral_constant<int, NT - 3>{}, 3);
-                else attn_part(std::integral_constant<int, 1>{}, g);
+                // A3: the same partial attention on pieces; every key chunk of a guest is a K = 16 product (one chain per feature tile)
+                auto attn_part3 = [&](auto njc, int J0) {
+                    constexpr int NJ = decltype(njc)::value;
+                    constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+                    u32x4 qb[3];
+                    u32x2 qc[3];
+                    u32x4 a0[NJ][3];
+                    u32x2 a2[NJ][3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        qb[pc] = reinterpret_cast<const u32x4*>(Qg)[pc * 64 + lane3];
+                        qc[pc] = reinterpret_cast<const u32x2*>(Qg + 192)[pc * 64 + lane3];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) k_load3(J0 + j, a0[j], a2[j]);
+                    // V^T pieces of key chunk J0 + j: a half of its pair's 16 bytes, or the odd last chunk
+                    u32x2 vh[NJ][NC][3];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int J = J0 + j;
+                        const bool oddc = (NT & 1) && J == NT - 1;
+#pragma unroll
+                        for (int t = 0; t < NC; ++t) {
+                            const u32x2* base = reinterpret_cast<const u32x2*>(Kimg + NT * KP_T16 + t * VP_T16);
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc)
+                                vh[j][t][pc] = oddc ? base[VP_PAIRS * 3 * 64 * 2 + pc * 64 + lane3] : base[(((J >> 1) * 3 + pc) * 64 + lane3) * 2 + (J & 1)];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f4 sc[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) sc[j] = tile48(std::false_type{}, a0[j], a2[j], qb, qc, splat4(0.f));
+                    float m0 = -3.0e38f, m1 = -3.0e38f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        m0 = fmaxf(fmaxf(m0, sc[j].x), sc[j].y);
+                        m1 = fmaxf(fmaxf(m1, sc[j].z), sc[j].w);
+                    }
+                    const float mraw = quad_max(fmaxf(m0, m1));
+                    const float m = mraw * scale;
+                    const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-mraw * SCALE_LOG2E, -mraw * SCALE_LOG2E};
+                    f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+                    u32x2 pp[NJ][3];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const f2 a = __builtin_elementwise_fma(f2{sc[j].x, sc[j].y}, k2, nm2);
+                        const f2 c = __builtin_elementwise_fma(f2{sc[j].z, sc[j].w}, k2, nm2);
+                        const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                        const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                        d0 += ea;
+                        d1 += ec;
+                        vt3::split3(f4{ea.x, ea.y, ec.x, ec.y}, pp[j][0], pp[j][1], pp[j][2]);
+                    }
+                    const f2 dd = d0 + d1;
+                    const float den = quad_sum(dd.x + dd.y);
+                    f4 o[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) o[t] = vt3::mma16(vh[j][t][TW[e]], pp[j][TX[e]], o[t]);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) Pg[(g * NC + t) * 64 + lane] = o[t];
+                    Mg[(g * 2 + 0) * 64 + lane] = m;
+                    Mg[(g * 2 + 1) * 64 + lane] = den;
+                };
+                if constexpr (A3) {
+                    if (g == 3) attn_part3(std::integral_constant<int, NT - 3>{}, 3);
+                    else attn_part3(std::integral_constant<int, 1>{}, g);
+                } else {
+                    if (g == 3) attn_part(std::integral_constant<int, NT - 3>{}, 3);
+                    else attn_part(std::integral_constant<int, 1>{}, g);
+                }
                 // guests-only rendezvous: every guest has published its partial
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_fetch_add(gflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -740,10 +1002,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     const float rl = __builtin_amdgcn_rcpf(Lsum);
 #pragma unroll
                     for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rl);
-                    f4 acc[1] = {splat4(0.f)};
-                    gemm_stage<NC, 1, true, true>([&](int c, opnd (&a)[1]) { a[0] = w_proj(g * NC + c); },
-                                                  [&](int c) { return o[c]; }, acc);
-                    Dg[g * 64 + lane] = acc[0];
+                    if constexpr (A3) {
+                        u32x4 ob[3], wa0[3];
+                        u32x2 oc[3], wa2[3];
+                        wp_load3(g, wa0, wa2);
+                        split_h3(o, ob, oc);
+                        Dg[g * 64 + lane] = tile48(std::false_type{}, wa0, wa2, ob, oc, splat4(0.f));
+                    } else {
+                        f4 acc[1] = {splat4(0.f)};
+                        gemm_stage<NC, 1, true, true>([&](int c, opnd (&a)[1]) { a[0] = w_proj(g * NC + c); },
+                                                      [&](int c) { return o[c]; }, acc);
+                        Dg[g * 64 + lane] = acc[0];
+                    }
                 }
             }
         }
@@ -1042,7 +1312,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) part[ot] = part[ot] + partB[ot];
 #pragma unroll
-                for (int ot = 0; ot < NC; ++ot) Pg[(g * NC + ot) * 64 + lane] = part[ot];
+                for (int ot = 0; ot < NC; ++ot) Pg2[(g * NC + ot) * 64 + lane] = part[ot];
             }
         } else if constexpr (WLDS) {
 #pragma unroll
@@ -1206,7 +1476,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + Pg[(k * NC + ot) * 64 + lane];
+                    for (int ot = 0; ot < NC; ++ot) x4[ot] = x4[ot] + Pg2[(k * NC + ot) * 64 + lane];
             }
         }
     }
