@@ -182,7 +182,11 @@ void vt_graph_destroy(vt_graph* g);
  * rounding (~4e-6), not bit for bit.  A caller that steps a group of N sequences as several models of N / k sequences each (one per
  * stream or per GPU: the reference shards sequences over worker processes, lib/test/evaluation/running.py:105-112) sets n = N on every
  * one of them: each shard then runs the forms the whole group would run, and a sequence's results do not depend on how the group is
- * sharded.  n = 0 (default): forms by each call's own batch.  A call with a batch larger than n uses its own batch. */
+ * sharded.  n = 0 (default): forms by each call's own batch.  A call with a batch larger than n uses its own batch.
+ * ORDER: the value applies to LATER calls only.  Set it before vt_set_template and before any vt_graph_capture[_steps]: the template
+ * cache holds the operands of the form it was written under (vt_forward(z = NULL) / vt_track_step return VT_ERR_STATE until
+ * vt_set_template has run again under the new value), and captured graphs keep the forms of their capture (changing the value on a
+ * model that has captured graphs returns VT_ERR_STATE). */
 int vt_set_form_batch(vt_model* m, int32_t n);
 
 /* Geometry / workspace queries (host side of build_box_head: feat_sz etc.). */

@@ -219,3 +219,19 @@ def test_form_batch_makes_a_small_batch_run_the_large_batch_forms(geom):
     assert float((plain["score_map"] - ob.score_map[:8]).abs().max()) < 1e-4
     with pytest.raises(native.VtError):
         small.set_form_batch(-1)
+    # ORDER rules of include/vittrack.h: the template cache and captured graphs belong to the form batch they were made under
+    z8, x8 = zd[:8].contiguous(), xd[:8].contiguous()
+    small.set_template(z8)
+    cached = small.forward(None, x8)
+    for k in keys:
+        assert torch.equal(getattr(cached, k), getattr(formed, k)), (geom, k)
+    small.set_form_batch(0)
+    with pytest.raises(native.VtError, match="form batch"):
+        small.forward(None, x8)                      # the cache holds the 256-forms' operands
+    small.set_template(z8)
+    small.forward(None, x8)
+    graph, _ = small.capture(z8, x8)
+    small.set_form_batch(0)                          # unchanged value: accepted
+    with pytest.raises(native.VtError, match="vt_graph_capture"):
+        small.set_form_batch(256)                    # the captured graph keeps the forms of its capture
+    del graph

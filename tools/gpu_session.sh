@@ -64,7 +64,7 @@ P
       timeout 600 python tools/race_check.py > $O/g128.txt 2>&1; tail -3 $O/g128.txt
       timeout 600 python tools/race_check.py --geom G256 --B 256 > $O/g256.txt 2>&1; tail -3 $O/g256.txt ;;
     trackstep)
-      timeout 600 python tracking/track_batch_demo.py --batch 256 > $O/g128.txt 2>&1; tail -4 $O/g128.txt
+      timeout 600 python tracking/track_batch_demo.py --batch 256 --geom G128 > $O/g128.txt 2>&1; tail -4 $O/g128.txt
       timeout 600 python tracking/track_batch_demo.py --batch 256 --geom G256 > $O/g256.txt 2>&1; tail -4 $O/g256.txt ;;
     generic)
       timeout 900 python -m pytest tests/test_gpu_generic.py -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -5 $O/pytest.txt ;;

@@ -18,10 +18,14 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="vit_48_h32_noKD")
+    ap.add_argument("--geom", default="", choices=["", "G128", "G256"],
+                    help="shorthand for --config: G128 = vit_48_h32_g128 (128 / 64 px, BASELINE's metric), G256 = vit_48_h32_noKD (the shipped YAML)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
     a = ap.parse_args()
+    if a.geom:
+        a.config = {"G128": "vit_48_h32_g128", "G256": "vit_48_h32_noKD"}[a.geom]
     import torch
     os.environ.setdefault("VITTRACK_PRJ_DIR", ROOT)
     from vittracker_amd.batched import BatchedVitTracker

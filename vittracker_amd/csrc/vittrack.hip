@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -93,6 +94,8 @@ struct vt_model {
     int blocks_tile = -1;            // 1 / 0 force the tile-parallel form of the blocks / forbid it, -1 (default): by batch size
     DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
     int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
+    int tmpl_form_batch = 0;         // the form batch vt_set_template ran under (the cache holds THAT form's operands)
+    int graphs_captured = 0;         // vt_graph_capture[_steps] calls that succeeded: their graphs hold the forms of their capture
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra capture streams for graph chains
@@ -587,14 +590,6 @@ int run_decode(vt_model* m, hipStream_t st, const float* score, const float* siz
     return VT_OK;
 }
 
-// the tail as its own launch (heads that decode inside their kernel)
-int run_tail(hipStream_t st, const float* hann, const float* conf, int B, const TrackTail& t) {
-    hipLaunchKernelGGL(vtt::update_state_kernel, dim3((B + 63) / 64), dim3(64), 0, st, hann, t.resize_factor, t.search_size, t.H, t.W,
-                       t.margin, B, t.states, conf, t.record);
-    HIP_TRY(hipGetLastError());
-    return VT_OK;
-}
-
 // F = 16: batches up to this size run conv1 as its own launch.  SWEEP_HEAD=1 tools/small_batch_sweep.py, us per step, per-tower
 // form -> split form: B=1 86.0 -> 78.6, B=8 96.6 -> 91.5, B=16 110.3 -> 103.5, B=32 135.2 -> 132.9, B=64 181.7 -> 186.2
 constexpr int HEAD_SPLIT_MAX_B = 32;
@@ -754,7 +749,11 @@ __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ sr
 // device serving byte-unaligned dword loads and on out-of-range buffer reads returning zero (tools/src/probe_unaligned.hip).  Neither
 // is architectural, so the first vt_create of a process crops a known frame with both forms -- device memory and device-mapped pinned
 // host memory (the plugin's zero-copy frames) -- and falls back to the byte-load form on any difference (round 3 advisor).
-int g_crop_bytes = -1;        // -1: not tested yet, 0: fast form, 1: byte-load form
+// The decision is per DEVICE (a process may drive several), taken once under a mutex by whichever vt_create or vt_crop gets there
+// first -- ViT-Base models included (round 4 advisor).
+constexpr int CROP_MAX_DEVICES = 64;
+int g_crop_bytes[CROP_MAX_DEVICES];        // 0: not tested yet, 1: fast form, 2: byte-load form
+std::mutex g_crop_mutex;
 
 void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const double* states, double factor, int T, const float* mean3,
                  const float* std3, int B, hipStream_t st, float* crops, double* rf) {
@@ -767,36 +766,55 @@ void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const do
                            std3[0], std3[1], std3[2], crops, rf);
 }
 
-int crop_selftest() {
-    if (g_crop_bytes >= 0) return VT_OK;
-    constexpr int H = 13, W = 17, T = 20, B = 2;          // odd sizes: windows at every byte alignment, crops across all four borders
-    std::vector<unsigned char> fr((size_t)B * H * W * 3);
-    for (size_t i = 0; i < fr.size(); ++i) fr[i] = (unsigned char)((i * 131u + (i >> 3) * 17u + 7u) & 0xffu);
-    const double st[B * 4] = {-2.5, -1.5, 9.0, 8.0, 9.5, 6.25, 9.0, 8.5};      // one box over the top-left corner, one over the bottom-right
-    const float mean3[3] = {0.485f, 0.456f, 0.406f}, std3[3] = {0.229f, 0.224f, 0.225f};
+// device buffers of the self test, released on every path
+struct CropProbe {
     unsigned char *dfr = nullptr, *hfr = nullptr;
     double *dst = nullptr, *drf = nullptr;
     float* dout = nullptr;
-    const size_t nout = (size_t)B * 3 * T * T;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dfr), fr.size()));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&hfr), fr.size(), hipHostMallocMapped));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), sizeof(st)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&drf), B * sizeof(double)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), 3 * nout * sizeof(float)));
-    HIP_TRY(hipMemcpy(dfr, fr.data(), fr.size(), hipMemcpyHostToDevice));
-    std::memcpy(hfr, fr.data(), fr.size());
-    HIP_TRY(hipMemcpy(dst, st, sizeof(st), hipMemcpyHostToDevice));
-    launch_crop(true, dfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout, drf);                  // the reference form
-    launch_crop(false, dfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout + nout, drf);          // fast form, device memory
-    launch_crop(false, hfr, H, W, dst, 2.0, T, mean3, std3, B, nullptr, dout + 2 * nout, drf);      // fast form, pinned host memory
-    HIP_TRY(hipGetLastError());
-    std::vector<float> out(3 * nout);
-    HIP_TRY(hipMemcpy(out.data(), dout, out.size() * sizeof(float), hipMemcpyDeviceToHost));
-    const bool same = std::memcmp(out.data(), out.data() + nout, nout * sizeof(float)) == 0 &&
-                      std::memcmp(out.data(), out.data() + 2 * nout, nout * sizeof(float)) == 0;
-    g_crop_bytes = same ? 0 : 1;
-    if (const char* v = std::getenv("VT_CROP_BYTES")) if (*v) g_crop_bytes = std::atoi(v) != 0;     // force a form (tests)
-    (void)hipFree(dfr); (void)hipHostFree(hfr); (void)hipFree(dst); (void)hipFree(drf); (void)hipFree(dout);
+    ~CropProbe() {
+        if (dfr) (void)hipFree(dfr);
+        if (hfr) (void)hipHostFree(hfr);
+        if (dst) (void)hipFree(dst);
+        if (drf) (void)hipFree(drf);
+        if (dout) (void)hipFree(dout);
+    }
+};
+
+// *bytes_form = whether the current device needs the byte-load form
+int crop_selftest(bool* bytes_form = nullptr) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= CROP_MAX_DEVICES) return fail(VT_ERR_ARG, "device index beyond the crop self test's table");
+    std::lock_guard<std::mutex> lock(g_crop_mutex);
+    if (g_crop_bytes[dev] == 0) {
+        constexpr int H = 13, W = 17, T = 20, B = 2;          // odd sizes: windows at every byte alignment, crops across all four borders
+        std::vector<unsigned char> fr((size_t)B * H * W * 3);
+        for (size_t i = 0; i < fr.size(); ++i) fr[i] = (unsigned char)((i * 131u + (i >> 3) * 17u + 7u) & 0xffu);
+        const double st[B * 4] = {-2.5, -1.5, 9.0, 8.0, 9.5, 6.25, 9.0, 8.5};      // one box over the top-left corner, one over the bottom-right
+        const float mean3[3] = {0.485f, 0.456f, 0.406f}, std3[3] = {0.229f, 0.224f, 0.225f};
+        CropProbe b;
+        const size_t nout = (size_t)B * 3 * T * T;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.dfr), fr.size()));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b.hfr), fr.size(), hipHostMallocMapped));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.dst), sizeof(st)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.drf), B * sizeof(double)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.dout), 3 * nout * sizeof(float)));
+        HIP_TRY(hipMemcpy(b.dfr, fr.data(), fr.size(), hipMemcpyHostToDevice));
+        std::memcpy(b.hfr, fr.data(), fr.size());
+        HIP_TRY(hipMemcpy(b.dst, st, sizeof(st), hipMemcpyHostToDevice));
+        launch_crop(true, b.dfr, H, W, b.dst, 2.0, T, mean3, std3, B, nullptr, b.dout, b.drf);                  // the reference form
+        launch_crop(false, b.dfr, H, W, b.dst, 2.0, T, mean3, std3, B, nullptr, b.dout + nout, b.drf);          // fast form, device memory
+        launch_crop(false, b.hfr, H, W, b.dst, 2.0, T, mean3, std3, B, nullptr, b.dout + 2 * nout, b.drf);      // fast form, pinned host memory
+        HIP_TRY(hipGetLastError());
+        std::vector<float> out(3 * nout);
+        HIP_TRY(hipMemcpy(out.data(), b.dout, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+        const bool same = std::memcmp(out.data(), out.data() + nout, nout * sizeof(float)) == 0 &&
+                          std::memcmp(out.data(), out.data() + 2 * nout, nout * sizeof(float)) == 0;
+        int form = same ? 1 : 2;
+        if (const char* v = std::getenv("VT_CROP_BYTES")) if (*v) form = std::atoi(v) != 0 ? 2 : 1;     // force a form (tests)
+        g_crop_bytes[dev] = form;
+    }
+    if (bytes_form) *bytes_form = g_crop_bytes[dev] == 2;
     return VT_OK;
 }
 
@@ -828,6 +846,7 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
     VbModel* vbm = nullptr;
     int rc = vb::create(cfg, &vbm, &err);
     if (rc) return fail(rc, err);
+    if ((rc = crop_selftest())) { vb::destroy(vbm); return rc; }      // every model kind can be handed to vt_crop (after the argument checks: they need no device)
     vt_model* m = new vt_model();
     m->vb = vbm;
     m->cfg = *cfg;
@@ -1291,6 +1310,9 @@ int vt_set_window(vt_model* m, const float* host_window) {
 int vt_set_form_batch(vt_model* m, int32_t n) {
     if (!m) return fail(VT_ERR_ARG, "null model");
     if (n < 0) return fail(VT_ERR_ARG, "vt_set_form_batch: n must be >= 0 (0 = choose the kernel forms by each call's own batch)");
+    if (n != m->form_batch && m->graphs_captured > 0)
+        return fail(VT_ERR_STATE, "vt_set_form_batch after vt_graph_capture: the captured graphs keep the forms of their capture -- set the form "
+                                  "batch before capturing (or use a fresh model)");
     m->form_batch = n;
     return VT_OK;
 }
@@ -1347,6 +1369,8 @@ int vt_forward(vt_model* m, const float* z_dev, const float* x_dev, int32_t B, v
         if (m->vb) return fail(VT_ERR_ARG, "the template cache is implemented for the vit_48 path only");
         if (m->tmpl_frames < B)
             return fail(VT_ERR_STATE, "vt_forward with a null template needs vt_set_template for at least " + std::to_string(B) + " frames first");
+        if (m->tmpl_form_batch != m->form_batch)
+            return fail(VT_ERR_STATE, "the template cache was written under another form batch: call vt_set_template again after vt_set_form_batch");
         if ((rc = run_stem(m, nullptr, x_dev, B, st, m->tokens_c.p, 0, 1))) return rc;
         if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
         return run_head(m, m->feat.p, B, st, out);
@@ -1375,6 +1399,7 @@ int vt_set_template(vt_model* m, const float* z_dev, int32_t B, void* stream) {
     // rows hold whatever the last cached frame left (per-token work, nothing of theirs is stored); the outputs are scratch.
     if ((rc = run_blocks(m, m->tokens_c.p, B, 1, st, m->feat.p, nullptr, 1))) return rc;
     m->tmpl_frames = B;
+    m->tmpl_form_batch = m->form_batch;
     return VT_OK;
 }
 
@@ -1391,7 +1416,9 @@ int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const 
     if (!m || !frames_dev || !states_dev || !crops_dev || !resize_factor_dev || !mean3 || !std3)
         return fail(VT_ERR_ARG, "null argument");
     if (B < 1 || H < 1 || W < 1 || out_size < 1 || !(factor > 0.0)) return fail(VT_ERR_ARG, "bad crop arguments");
-    launch_crop(g_crop_bytes == 1, frames_dev, H, W, states_dev, factor, out_size, mean3, std3, B, static_cast<hipStream_t>(stream), crops_dev,
+    bool crop_bytes = false;
+    if (int rcs = crop_selftest(&crop_bytes)) return rcs;      // a table look-up after the device's first call
+    launch_crop(crop_bytes, frames_dev, H, W, states_dev, factor, out_size, mean3, std3, B, static_cast<hipStream_t>(stream), crops_dev,
                 resize_factor_dev);
     HIP_TRY(hipGetLastError());
     return VT_OK;
@@ -1424,6 +1451,8 @@ int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, doub
     if (m->vb) return fail(VT_ERR_ARG, "vt_track_step is implemented for the vit_48 path only");
     if (m->tmpl_frames < B)
         return fail(VT_ERR_STATE, "vt_track_step needs vt_set_template for at least " + std::to_string(B) + " frames first");
+    if (m->tmpl_form_batch != m->form_batch)
+        return fail(VT_ERR_STATE, "the template cache was written under another form batch: call vt_set_template again after vt_set_form_batch");
     if (!states_dev) return fail(VT_ERR_ARG, "null argument");
     if ((rc = vt_crop(m, frames, H, W, states_dev, factor, m->cfg.search_size, mean3, std3, B, stream, crops_dev, resize_factor_dev))) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1496,6 +1525,7 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
     e = hipGraphInstantiate(&vg->exec, vg->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(vg->graph); delete vg; return fail(VT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
     *g = vg;
+    ++m->graphs_captured;
     return VT_OK;
 }
 
