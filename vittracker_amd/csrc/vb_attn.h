@@ -15,6 +15,10 @@
 #pragma once
 #include "vb_gemm.h"
 
+#ifndef VB_ATTN_DBG
+#define VB_ATTN_DBG 0       // timing experiments only (wrong results): 1 = no q.k / softmax / P.V (staging, q loads and stores only),
+#endif                      // 2 = no K / V^T staging (the arithmetic on whatever the LDS holds)
+
 namespace vba {
 
 using vbg::bf16;
@@ -61,12 +65,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
     load_q(w + 4, qfrag[1]);
     // ---- stage K (rows permuted) and V^T
     const int pl = vbg::swz_byte(lane * 16), prow = pl >> 6, pk = (pl & 63) >> 1;
-    for (int s = w; s < G::K_SUB; s += 4) {
+    for (int s = w; s < (VB_ATTN_DBG == 2 ? 0 : G::K_SUB); s += 4) {
         const int t = s / G::KS, ks = s - t * G::KS;
         const int key = 32 * (t >> 1) + 8 * (prow >> 2) + (prow & 3) + 4 * (t & 1);
         vbg::glds16(kf + (size_t)key * 2 * C + ks * 32 + pk, Kimg + s * 1024 + lane * 16);
     }
-    for (int s = w; s < G::V_SUB; s += 4) {
+    for (int s = w; s < (VB_ATTN_DBG == 2 ? 0 : G::V_SUB); s += 4) {
         const int dt = s / G::NC, c = s - dt * G::NC;
         vbg::glds16(vf + (size_t)(dt * 16 + prow) * L + c * 32 + pk, Vimg + s * 1024 + lane * 16);
     }
@@ -91,6 +95,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16* __restrict__ q
         int frq = fr;
         asm volatile("" : "+v"(frq));
         f4 S[NQ][G::NT];
+        if constexpr (VB_ATTN_DBG == 1) {
+            if constexpr (NXT >= 1) load_q(nx0, qfrag[0]);
+            if constexpr (NXT >= 2) load_q(nx1, qfrag[1]);
+            if (!v_ready) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); v_ready = true; }
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                bf16* o = out + (size_t)(f * L + qts[u] * 16 + l15) * C + h * HD + q * 4;
+#pragma unroll
+                for (int dt = 0; dt < G::DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = bf16x4{qfrag[u][0][0], qfrag[u][0][1], qfrag[u][1][0], qfrag[u][1][1]};
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < G::NT; ++t) {
 #pragma unroll
