@@ -40,13 +40,17 @@ typedef struct vt_graph vt_graph;
 /* Replaces the cfg fields read by build_ostrack_dist (lib/models/vit_dist/vit_dist.py:159-164)
  * and build_box_head CENTER (lib/models/layers/head.py:352-359).
  *
- * SUPPORTED SHAPES.  The reference builds from any cfg; vt_create accepts exactly three and rejects every other combination with
- * VT_ERR_ARG and a message naming them:
- *     channels 48,  heads 1,  head_channels 32,  stride 16, (template, search) = (64, 128) or (128, 256), depth 1..12   -- vit_48_h32
+ * SUPPORTED SHAPES.  The reference builds from any cfg (lib/models/vit_dist/vit_dist.py:159-198; lib/utils/ce_utils.py:22-32 lists
+ * template feature sizes 8 / 12 / 7 / 14).  vt_create accepts:
+ *     channels 48,  heads 1,  head_channels 32,  stride 16, depth 1..12, (template, search) = ANY multiples of 16 in [16, 512]  -- vit_48_h32
+ *         (64, 128) and (128, 256): the tuned kernels (every form of DESIGN.md section 4: MFMA, LDS-resident maps, hipGraph-sized forms)
+ *         every other geometry -- e.g. (112, 224), (192, 384); token counts need not be multiples of 16 -- runs the shape-generic
+ *         kernels of vt_generic.h: plain fp32, one thread per output value, reference-implementation speed, the same outputs and the
+ *         whole ABI (stages, template cache, graphs, vt_crop / vt_track_step)
  *     channels 768, heads 12, head_channels 256, stride 16, (template, search) = (128, 256), depth 12                   -- ViT-Base
- * The kernels are specialised on their tile counts (token tiles per frame, feature chunks, map sides are template parameters --
- * that is where their register blocking comes from), so `heads` and the crop sizes are NOT run-time parameters of a kernel: another
- * geometry is a new instantiation plus its LDS plan. */
+ * and rejects every other combination with VT_ERR_ARG and a message naming these.  The tuned kernels are specialised on their tile
+ * counts (token tiles per frame, feature chunks, map sides are template parameters -- that is where their register blocking comes
+ * from), so `heads` and the crop sizes are NOT run-time parameters of THOSE kernels. */
 typedef struct vt_config {
     int32_t template_size; /* DATA.TEMPLATE.SIZE  (128; 64 for G128) */
     int32_t search_size;   /* DATA.SEARCH.SIZE    (256; 128 for G128) */

@@ -24,6 +24,7 @@
 #define VT_SEQ3_MAXP 2      // head_seq3: conv1 weight pairs per register pass
 #endif
 #include "vt_head3.h"
+#include "vt_generic.h"
 #include "vt_stem.h"
 #include "vt_stem_fused.h"
 #include "vt_stem_stream.h"
@@ -66,6 +67,13 @@ constexpr int STEM_CH[5] = {3, 6, 12, 24, 48};
 
 struct vt_model {
     VbModel* vb = nullptr;           // ViT-Base path (channels = 768): backbone + head towers live in vitb.hip
+    // any other stride-16 geometry of the vit_48_h32 surface: the shape-generic kernels of vt_generic.h
+    bool generic = false;
+    DevBuf g_stem_w[4], g_stem_b[4]; // folded conv weights [cout][cin][9] / bias
+    DevBuf g_blocks;                 // depth * vtg::GEN_BLOCK_STRIDE + 2 C (final norm)
+    DevBuf g_head;                   // 3 * vtg::GEN_TOWER_STRIDE
+    DevBuf g_a, g_b;                 // stem ping-pong maps; then the head's
+    DevBuf g_qkv, g_ao, g_hid, g_x;  // (B L, 3 C), (B L, C), (B L, 4 C); the residual stream being updated
     vt_config cfg{};
     int len_z = 0, len_x = 0, L = 0, F = 0, Fz = 0;
     bool weights_loaded = false;
@@ -368,9 +376,74 @@ StemPlan stem_plan_default(int T) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------- shape-generic path (vt_generic.h)
+inline unsigned gen_grid(size_t n) { return (unsigned)((n + 255) / 256); }
+
+int gen_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, int zmode) {
+    for (int side = 0; side < 2; ++side) {       // 0: template rows, 1: search rows
+        const float* img = side == 0 ? z : x;
+        if ((side == 0 && zmode == 1) || (side == 1 && zmode == 2) || !img) continue;
+        const int T = side == 0 ? m->cfg.template_size : m->cfg.search_size;
+        const float* in = img;
+        int S = T;
+        for (int i = 0; i < 4; ++i) {
+            const int cin = STEM_CH[i], cout = STEM_CH[i + 1], So = S / 2;
+            float* out = (i & 1) ? m->g_b.p : m->g_a.p;
+            const size_t total = (size_t)B * cout * So * So;
+            hipLaunchKernelGGL(vtg::stem_conv_kernel, dim3(gen_grid(total)), dim3(256), 0, st, in, m->g_stem_w[i].p, m->g_stem_b[i].p, B, cin, cout, S,
+                               i < 3 ? out : nullptr, i < 3 ? nullptr : tokens, side == 0 ? m->pos_z.p : m->pos_x.p, m->L, side == 0 ? 0 : m->len_z);
+            in = out;
+            S = So;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int gen_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid) {
+    if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
+    const size_t rows = (size_t)B * m->L;
+    // the residual stream is updated in place in a buffer of its own: the caller's tokens -- and the cached template rows of
+    // vt_set_template's token matrix -- stay untouched
+    float* x = m->g_x.p;
+    HIP_TRY(hipMemcpyAsync(x, tokens, rows * 48 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < nblocks; ++i) {
+        const float* P = m->g_blocks.p + (size_t)i * vtg::GEN_BLOCK_STRIDE;
+        hipLaunchKernelGGL(vtg::ln_linear_kernel<0>, dim3(gen_grid(rows * 144)), dim3(256), 0, st, x, P + vtg::GO_WQKV, P + vtg::GO_BQKV, rows, 144, m->g_qkv.p);
+        hipLaunchKernelGGL(vtg::attn_kernel, dim3(gen_grid(rows)), dim3(256), 0, st, m->g_qkv.p, B, m->L, m->g_ao.p);
+        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * 48)), dim3(256), 0, st, m->g_ao.p, P + vtg::GO_WPROJ, P + vtg::GO_BPROJ, rows, 48, x);
+        hipLaunchKernelGGL(vtg::ln_linear_kernel<1>, dim3(gen_grid(rows * 192)), dim3(256), 0, st, x, P + vtg::GO_W1, P + vtg::GO_B1, rows, 192, m->g_hid.p);
+        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * 48)), dim3(256), 0, st, m->g_hid.p, P + vtg::GO_W2, P + vtg::GO_B2, rows, 192, x);
+    }
+    if (resid) HIP_TRY(hipMemcpyAsync(resid, x, rows * 48 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const float* N = m->g_blocks.p + (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE;
+    hipLaunchKernelGGL(vtg::final_norm_kernel, dim3(gen_grid((size_t)B * m->len_x * 48)), dim3(256), 0, st, x, N, N + 48, B, m->L, m->len_z, feat);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int gen_head(vt_model* m, const float* feat, int B, hipStream_t st, float* score, float* size, float* offset) {
+    const int F = m->F;
+    const size_t npx = (size_t)B * F * F;
+    const float* in = feat;
+    size_t in_stride = 0;
+    for (int i = 0; i < 4; ++i) {
+        float* out = (i & 1) ? m->g_b.p : m->g_a.p;
+        hipLaunchKernelGGL(vtg::head_conv_kernel, dim3(gen_grid(3 * npx * vtg::HCH[i + 1])), dim3(256), 0, st, in, in_stride, m->g_head.p, vtg::HO_W[i],
+                           vtg::HO_B[i], B, F, vtg::HCH[i], vtg::HCH[i + 1], out);
+        in = out;
+        in_stride = npx * vtg::HCH[i + 1];
+    }
+    hipLaunchKernelGGL(vtg::head_out_kernel, dim3(gen_grid(npx)), dim3(256), 0, st, in, m->g_head.p, B, F, score, size, offset);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
 int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0, int zmode = 0) {
     // f0: first frame of this slice in the model workspace (z, x, tokens already point at the slice)
     // zmode 0: both crops; 1: search crop only (template token rows already in `tokens`); 2: template crop only
+    if (m->generic) return gen_stem(m, z, x, B, st, tokens, zmode);
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
     float* const act_z = m->act_z.p + f0 * (size_t)(Tz / 4) * (Tz / 4) * 12;
@@ -542,6 +615,8 @@ int launch_blocks_tile(vt_model* m, hipStream_t st, const float* tokens, int B, 
 int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t st, float* feat, float* resid, int zc = 0, size_t f0 = 0) {
     // zc: template cache mode of block 0 (0 off, 1 store, 2 load); f0: first frame of this slice in the model workspace
     if (zc != 0 && f0 != 0) return fail(VT_ERR_STATE, "the template cache is not sliced");
+    if (m->generic) return zc == 1 ? VT_OK      // vt_set_template: the template's token rows are the cache; block 0 is recomputed every frame
+                                   : gen_blocks(m, tokens, B, nblocks, st, feat, resid);
     if (nblocks < 0 || nblocks > m->cfg.depth) nblocks = m->cfg.depth;
     // Kernel form by batch size: with few frames a workgroup per frame leaves most of the chip idle (a frame's latency is one
     // CU's worth of MFMA issue); one wave per tile spreads frames x tiles over the SIMDs instead.
@@ -603,6 +678,10 @@ int run_head(vt_model* m, const float* feat, int B, hipStream_t st, const vt_out
     float* pred = ((o && o->pred_boxes) ? o->pred_boxes : m->pred.p) + f0 * 4;
     float* hann = ((o && o->hann_boxes) ? o->hann_boxes : m->hann.p) + f0 * 4;
     float* conf = ((o && o->conf) ? o->conf : m->conf.p) + f0;
+    if (m->generic) {
+        if (int rcg = gen_head(m, feat, B, st, score, size, offset)) return rcg;
+        return run_decode(m, st, score, size, offset, m->window.p, B, pred, hann, conf, tail);
+    }
     const int Bf = form_b(m, B);
 #ifndef VT_F16
     if (m->F == 8 && m->head_bf3 && !m->skip_head) {       // three-piece bf16 towers (vt_head3.h), same kernel forms by batch size
@@ -922,11 +1001,14 @@ int vt_create(const vt_config* cfg, vt_model** out) {
                         std::to_string(cfg->heads) + " head_channels=" + std::to_string(cfg->head_channels));
     const bool g128 = cfg->template_size == 64 && cfg->search_size == 128;
     const bool g256 = cfg->template_size == 128 && cfg->search_size == 256;
-    if (!g128 && !g256)
+    const bool generic = !g128 && !g256;
+    if (generic && (cfg->template_size % 16 != 0 || cfg->search_size % 16 != 0 || cfg->template_size < 16 || cfg->search_size < 16 ||
+                    cfg->template_size > 512 || cfg->search_size > 512))
         return fail(VT_ERR_ARG, "unsupported geometry (template,search)=(" + std::to_string(cfg->template_size) + "," +
-                                    std::to_string(cfg->search_size) + "); supported: (64,128), (128,256)");
+                                    std::to_string(cfg->search_size) + "): sizes must be multiples of 16 in [16, 512]; tuned kernels exist for (64,128) and "
+                                    "(128,256), every other size runs the shape-generic kernels");
     if (cfg->depth < 1 || cfg->depth > 12 || cfg->max_batch < 1) return fail(VT_ERR_ARG, "bad depth / max_batch");
-    {   // the block kernel keeps every block's LayerNorm vectors and biases in LDS next to the K/V images
+    if (!generic) {   // the block kernel keeps every block's LayerNorm vectors and biases in LDS next to the K/V images
         const size_t need = g128 ? blocks_lds_bytes(5, true, true, cfg->depth) : blocks_lds_bytes(20, false, false, cfg->depth);
         if (need > LDS_PER_CU)
             return fail(VT_ERR_ARG, "depth " + std::to_string(cfg->depth) + " needs " + std::to_string(need) +
@@ -944,18 +1026,30 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     const size_t B = (size_t)cfg->max_batch;
     int rc = VT_OK;
     auto A = [&](DevBuf& d, size_t n) { if (!rc) rc = d.alloc(n); };
-    A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
-    A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
+    m->generic = generic;
     A(m->tokens, B * m->L * 48);
     A(m->feat, B * m->len_x * 48);
     A(m->tokens_c, B * m->L * 48);
+    if (generic) {
+        const size_t T = (size_t)std::max(cfg->search_size, cfg->template_size);
+        // ping-pong maps: stem layers 1 / 3 and head convs 1 / 3 in g_a, layers 2 and convs 2 / 4 in g_b
+        A(m->g_a, std::max(B * 6 * (T / 2) * (T / 2), 3 * B * (size_t)m->len_x * 32));
+        A(m->g_b, std::max(B * 12 * (T / 4) * (T / 4), 3 * B * (size_t)m->len_x * 16));
+        A(m->g_qkv, B * m->L * 144);
+        A(m->g_ao, B * m->L * 48);
+        A(m->g_hid, B * m->L * 192);
+        A(m->g_x, B * m->L * 48);
+    } else {
+    A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
+    A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
     A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
     m->tile_frames = (int)std::min<size_t>(B, 128);
     A(m->tile_q, 2 * (size_t)m->tile_frames * m->L * 48);      // two sets each (launch_blocks_tile)
     A(m->tile_k, 2 * (size_t)m->tile_frames * m->L * 48);
     A(m->tile_v, 2 * (size_t)m->tile_frames * m->L * 48);
     A(m->tile_x, (size_t)m->tile_frames * m->L * 48);
-    if (m->F == 16) {
+    }
+    if (!generic && m->F == 16) {
         m->head_m1_frames = (int)std::min<size_t>(B, 176);
         A(m->head_m1, (size_t)m->head_m1_frames * 3 * 8 * vth::Geo<16>::NPIX * 4);
         if (!rc && hipMemset(m->head_m1.p, 0, m->head_m1.n * sizeof(float)) != hipSuccess) rc = fail(VT_ERR_HIP, "hipMemset(head_m1) failed");
@@ -988,7 +1082,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     m->stem_bf3 = env_int("VT_STEM_BF3", 1);
-    {
+    if (!generic) {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
         const char* v = std::getenv("VT_STEM_R4_128");
@@ -1112,6 +1206,9 @@ void vt_destroy(vt_model* m) {
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();
+    for (int i = 0; i < 4; ++i) { m->g_stem_w[i].release(); m->g_stem_b[i].release(); }
+    DevBuf* gen[] = {&m->g_blocks, &m->g_head, &m->g_a, &m->g_b, &m->g_qkv, &m->g_ao, &m->g_hid, &m->g_x};
+    for (DevBuf* d : gen) d->release();
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (int i = 0; i < 3; ++i) {
         if (m->side_stream[i]) (void)hipStreamDestroy(m->side_stream[i]);
@@ -1140,6 +1237,11 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         const std::string p = "patch_embed.net." + std::to_string(2 * i);
         std::vector<double> w, b;
         if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
+        if (m->generic) {      // plain [cout][cin][9] weights for vt_generic.h; none of the tuned kernels' images
+            if ((rc = upload(m->g_stem_w[i], std::vector<float>(w.begin(), w.end())))) return rc;
+            if ((rc = upload(m->g_stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+            continue;
+        }
         if (i < 1) {   // VALU layer: [r][cin][s][cout] sections, weights become scalar operands
             if ((rc = upload(m->stem_w[i], pack_conv_sections(w, STEM_CH[i + 1], STEM_CH[i])))) return rc;
             if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
@@ -1185,6 +1287,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     // ---- transformer blocks + final norm
     std::vector<float> bp((size_t)m->cfg.depth * vtb::BLOCK_STRIDE + 2 * C);
     std::vector<uint16_t> bp3((size_t)m->cfg.depth * vtb::BLOCK3_STRIDE * 2, 0);
+    std::vector<float> gbp(m->generic ? (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE + 2 * C : 0);      // vt_generic.h: plain [out][in] weights
     for (int b = 0; b < m->cfg.depth; ++b) {
         const std::string pre = "blocks." + std::to_string(b) + ".";
         float* dst = bp.data() + (size_t)b * vtb::BLOCK_STRIDE;
@@ -1199,7 +1302,8 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         }
         // norm1 -> qkv and norm2 -> fc1: the LayerNorm's affine part is folded into the linear layer that consumes it, in
         // double (y = W (gamma * n + beta) + b = (W diag gamma) n + (b + W beta)); the kernels normalise only (vt_blocks.h).
-        auto fold_ln = [&](const char* wname, int out, int o_ln_g, int o_ln_b, int o_bias, int o_w) -> int {
+        float* gdst = m->generic ? gbp.data() + (size_t)b * vtg::GEN_BLOCK_STRIDE : nullptr;
+        auto fold_ln = [&](const char* wname, int out, int o_ln_g, int o_ln_b, int o_bias, int o_w, int go_w, int go_b) -> int {
             const float* W;
             int rc2 = need(tm, pre + wname, (int64_t)out * C, &W);
             if (rc2) return rc2;
@@ -1213,14 +1317,20 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
                 dst[o_bias + o] = (float)acc;
             }
             pack_linear_image(wf.data(), out, C, dst + o_w);
+            if (gdst) {
+                std::memcpy(gdst + go_w, wf.data(), wf.size() * sizeof(float));
+                std::memcpy(gdst + go_b, dst + o_bias, out * sizeof(float));
+            }
             return VT_OK;
         };
-        if ((rc = fold_ln("attn.qkv.weight", 3 * C, vtb::O_LN1G, vtb::O_LN1B, vtb::O_BQKV, vtb::O_WQKV))) return rc;
+        if ((rc = fold_ln("attn.qkv.weight", 3 * C, vtb::O_LN1G, vtb::O_LN1B, vtb::O_BQKV, vtb::O_WQKV, vtg::GO_WQKV, vtg::GO_BQKV))) return rc;
         if ((rc = need(tm, pre + "attn.proj.weight", C * C, &p))) return rc;
         pack_linear_image(p, C, C, dst + vtb::O_WPROJ);
-        if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
+        if (gdst) { std::memcpy(gdst + vtg::GO_WPROJ, p, (size_t)C * C * sizeof(float)); std::memcpy(gdst + vtg::GO_BPROJ, dst + vtb::O_BPROJ, C * sizeof(float)); }
+        if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1, vtg::GO_W1, vtg::GO_B1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
+        if (gdst) { std::memcpy(gdst + vtg::GO_W2, p, (size_t)4 * C * C * sizeof(float)); std::memcpy(gdst + vtg::GO_B2, dst + vtb::O_B2, C * sizeof(float)); }
         pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, dst + vtb::O_WQKV, dst + vtb::O_WPROJ, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
     }
     {
@@ -1229,6 +1339,10 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst, p, C * sizeof(float));
         if ((rc = need(tm, "norm.bias", C, &p))) return rc;
         std::memcpy(dst + C, p, C * sizeof(float));
+    }
+    if (m->generic) {
+        std::memcpy(gbp.data() + (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE, bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE, 2 * C * sizeof(float));
+        if ((rc = upload(m->g_blocks, gbp))) return rc;
     }
     if ((rc = upload(m->blocks, bp))) return rc;
 #ifdef VT_F16
@@ -1252,6 +1366,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
 #endif
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
+    std::vector<float> ghp(m->generic ? (size_t)3 * vtg::GEN_TOWER_STRIDE : 0, 0.f);
 #ifndef VT_F16
     std::vector<uint16_t> hp3((size_t)3 * vth3::TOWER3_STRIDE * 8, 0);
 #endif
@@ -1275,6 +1390,11 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             }
 #endif
             for (int o = 0; o < chans[i + 1]; ++o) dst[boff[i] + o] = (float)b[o];
+            if (m->generic) {
+                float* g = ghp.data() + (size_t)t * vtg::GEN_TOWER_STRIDE;
+                for (size_t k = 0; k < w.size(); ++k) g[vtg::HO_W[i] + k] = (float)w[k];
+                for (int o = 0; o < chans[i + 1]; ++o) g[vtg::HO_B[i] + o] = (float)b[o];
+            }
         }
         const int nout = t == 0 ? 1 : 2;
         const std::string c5 = std::string("box_head.conv5_") + towers[t];
@@ -1282,7 +1402,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + vth::O_W5, p, nout * 4 * sizeof(float));
         if ((rc = need(tm, c5 + ".bias", nout, &p))) return rc;
         std::memcpy(dst + vth::O_B5, p, nout * sizeof(float));
+        if (m->generic) {
+            float* g = ghp.data() + (size_t)t * vtg::GEN_TOWER_STRIDE;
+            std::memcpy(g + vtg::HO_W5, dst + vth::O_W5, nout * 4 * sizeof(float));
+            std::memcpy(g + vtg::HO_B5, dst + vth::O_B5, nout * sizeof(float));
+        }
     }
+    if (m->generic && (rc = upload(m->g_head, ghp))) return rc;
     if ((rc = upload(m->head, hp))) return rc;
 #ifdef VT_F16
     for (int t = 0; t < 3; ++t)      // the towers' conv images as stored operands, in place (biases and conv5 stay float)
