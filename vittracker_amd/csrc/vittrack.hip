@@ -563,6 +563,8 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
 // dynamic LDS of blocks_kernel<NT, ., ., WLDS, BAL> at a given depth: K/V images, weight staging buffers,
 // the small parameters (LayerNorm vectors + biases of every block) and the guests' exchange area
 size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth, bool BF3 = false, bool A3 = false) {
+    if (A3 && !WLDS)    // the G256 form: K as pieces, V^T an fp32 image, no staging buffers, no guests
+        return ((size_t)NT * vtb::W3_FC1_OT16 + (size_t)vtb::NC * NT * 64) * sizeof(f4) + (size_t)vtb::small_floats(depth) * sizeof(float);
     if (A3)     // K / V^T as pieces (vt_blocks.h: KV_UNITS); of the guests' areas only Dg and the counter keep room of their own
         return ((size_t)NT * vtb::W3_FC1_OT16 + (size_t)vtb::NC * ((NT / 2) * 3 * 64 + (NT & 1) * 3 * 32) +
                 (size_t)(vtb::W3_FC1_TILES + vtb::WBUF_TILES) * 64) * sizeof(f4) +
@@ -645,6 +647,9 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
                                   : launch_blocks<5, 5, 1, false>(m, st, tokens, B, nblocks, feat, resid, zc);
         case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
 #ifndef VT_F16
+            if (m->blocks_bal && m->blocks_bf3_g256 >= 2)
+                return zc ? launch_blocks<20, 8, 3, false, false, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
+                          : launch_blocks<20, 8, 3, false, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
             if (m->blocks_bal && m->blocks_bf3_g256)
                 return zc ? launch_blocks<20, 8, 3, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                           : launch_blocks<20, 8, 3, false, false, false, true>(m, st, tokens, B, nblocks, feat, resid, zc);
@@ -1070,6 +1075,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->blocks_bal = env_int("VT_BLOCKS_BAL", 1);
     m->blocks_bf3 = env_int("VT_BLOCKS_BF3", 2);
     m->blocks_bf3_g256 = m->blocks_bf3;
+    if (m->blocks_bf3_g256 >= 2 && blocks_lds_bytes(20, false, false, cfg->depth, true, true) > LDS_PER_CU) m->blocks_bf3_g256 = 1;
     if (m->blocks_bf3 >= 2 && blocks_lds_bytes(5, true, true, cfg->depth, true, true) > LDS_PER_CU) m->blocks_bf3 = 1;
     // the BF3 form's staging buffers are 18 KiB larger: beyond depth 8 its small parameters no longer fit beside them -> fp32 form
     if (blocks_lds_bytes(5, true, true, cfg->depth, true) > LDS_PER_CU) m->blocks_bf3 = 0;
@@ -1144,6 +1150,12 @@ int vt_create(const vt_config* cfg, vt_model** out) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth));
+        if (e == hipSuccess && m->blocks_bf3_g256 >= 2)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth, true, true));
+        if (e == hipSuccess && m->blocks_bf3_g256 >= 2)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vtb::blocks_kernel<20, 8, 3, false, false, true, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)blocks_lds_bytes(20, false, false, cfg->depth, true, true));
 #endif
 
         (void)small_bytes;

@@ -259,16 +259,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     constexpr bool BF3L = BF3 && WLDS, BF3G = BF3 && !WLDS;
     static_assert(!BF3L || (BAL && 2 * NT * NC >= W3_FC2_TILES - WBUF_TILES), "BF3 with staging: written for the balanced frame form; fc2's third output tile is staged in the K / V area");
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
-    static_assert(!A3 || BF3L, "A3: written for the staged three-piece form");
-    // A3: 16-byte units per key tile of the K pieces / per feature tile of the V^T pieces
+    static_assert(!A3 || BF3, "A3: written for the three-piece forms");
+    // A3: 16-byte units per key tile of the K pieces / per feature tile of the V^T pieces.  VP3 = V^T as pieces too (the staged G128 form);
+    // the G256 form (BF3G) has LDS for the K pieces only (90 KiB) beside the fp32 V^T image (60 KiB): q k^T and proj run on the bf16 pipe,
+    // P.V stays on fp32 MFMAs
+    constexpr bool VP3 = A3 && BF3L;
     constexpr int KP_T16 = W3_FC1_OT16, VP_PAIRS = NT / 2, VP_T16 = VP_PAIRS * 3 * 64 + (NT & 1) * 3 * 32;
-    constexpr int KV_UNITS = A3 ? NT * KP_T16 + NC * VP_T16 : 2 * NT * NC * 64;
+    constexpr int KV_UNITS = A3 ? NT * KP_T16 + (VP3 ? NC * VP_T16 : NC * NT * 64) : 2 * NT * NC * 64;
     constexpr int L = NT * 16;
     constexpr int NOWN = BAL ? NT - 1 : NT;                // tiles handled by owner waves
     constexpr int GT = NT - 1;                             // BAL: the guests' tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     f4* Kimg = reinterpret_cast<f4*>(lds);                 // [NT][NC][64]   (BF3L: also fc2's third output tile, as pieces)
-    f4* Vimg = Kimg + NT * NC * 64;                        // [NC][NT][64]
+    f4* Vimg = Kimg + (A3 ? NT * KP_T16 : NT * NC * 64);   // [NC][NT][64]   (A3: behind the K pieces; VP3: pieces, addressed from Kimg)
     // the K and V^T images as STORED operands (f16 build: h4, half the bytes of the same area; written once per block, read by every wave)
     opnd* const Ko = reinterpret_cast<opnd*>(Kimg);
     opnd* const Vo = reinterpret_cast<opnd*>(Vimg);
@@ -431,11 +434,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 a2[pc] = Kp3h[J * KP_T16 * 2 + pc * 64];
             }
         };
-        auto wp_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {       // proj pieces of output tile t (buffer B, fc1's layout)
+        auto wp_load3 = [&](int t, u32x4 (&a0)[3], u32x2 (&a2)[3]) {       // proj pieces of output tile t (fc1's layout): buffer B, or straight from L2 (BF3G)
+            if constexpr (BF3L) {
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                a0[pc] = Wb3[t * W3_FC1_OT16 + pc * 64];
-                a2[pc] = reinterpret_cast<const u32x2*>(Wb)[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                for (int pc = 0; pc < 3; ++pc) {
+                    a0[pc] = Wb3[t * W3_FC1_OT16 + pc * 64];
+                    a2[pc] = reinterpret_cast<const u32x2*>(Wb)[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                }
+            } else {
+                const u32x4* const Gp = reinterpret_cast<const u32x4*>(P3) + (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 64;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    a0[pc] = Gp[t * W3_FC1_OT16 + pc * 64 + lane3];
+                    a2[pc] = reinterpret_cast<const u32x2*>(Gp)[(t * W3_FC1_OT16 + 192) * 2 + pc * 64 + lane3];
+                }
             }
         };
         auto store_k3 = [&](f4* dst_tile, const f4 (&kr)[NC]) {            // a token tile's k (or the guests' q) as pieces: one "output tile" of fc1's layout
@@ -446,6 +458,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             for (int pc = 0; pc < 3; ++pc) {
                 reinterpret_cast<u32x4*>(dst_tile)[pc * 64 + lane3] = kb[pc];
                 reinterpret_cast<u32x2*>(dst_tile + 192)[pc * 64 + lane3] = kc[pc];
+            }
+        };
+        auto store_k3c = [&](f4* dst_tile, int ot, f4 r) {                  // the same, one feature chunk at a time (no three-chunk collection)
+            u32x2 pk[3];
+            vt3::split3(r, pk[0], pk[1], pk[2]);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                if (ot < 2) reinterpret_cast<u32x2*>(dst_tile)[(pc * 64 + lane3) * 2 + ot] = pk[pc];
+                else reinterpret_cast<u32x2*>(dst_tile + 192)[pc * 64 + lane3] = pk[pc];
             }
         };
         // unit offset (u32x2) of key chunk J's half inside feature tile t's V^T pieces, piece pc at + pc * 128 (pair) / + pc * 64 (odd chunk)
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 for (int pc = 0; pc < 3; ++pc) base[(((T >> 1) * 3 + pc) * 64 + lane3) * 2 + (T & 1)] = pv[pc];
             }
         };
-        if constexpr (A3) {
+        if constexpr (A3 && BF3L) {
             stage_tiles(Wb, P3 + (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 256, W3_PROJ_TILES, w, NW, lane, blk == 0);
         } else if constexpr (BF3L) {
             stage_tiles(Wb, P + O_WPROJ, PROJ_TILES, w, NW, lane, blk == 0);
@@ -482,12 +503,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
                     qr[i][ot] = zc[ot * 64];
-                    if constexpr (A3) {
-                        store_v3(T, ot, zc[(2 * NC + ot) * 64]);
-                    } else {
-                        Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
-                        Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
-                    }
+                    if constexpr (VP3) store_v3(T, ot, zc[(2 * NC + ot) * 64]);
+                    else Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
+                    if constexpr (!A3) Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
                 }
                 if constexpr (A3) {
                     f4 kr[NC];
@@ -540,9 +558,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                         if (t < NC) qr[i][ot] = r;
                         else if constexpr (A3) {
                             if (t < 2 * NC) {
-                                kr[ot] = r;
-                                if (ot == NC - 1) store_k3(Kimg + T * KP_T16, kr);
-                            } else store_v3(T, ot, r);
+                                if constexpr (VP3) {
+                                    kr[ot] = r;
+                                    if (ot == NC - 1) store_k3(Kimg + T * KP_T16, kr);
+                                } else store_k3c(Kimg + T * KP_T16, ot, r);      // the 20-tile form has no registers for kr
+                            } else if constexpr (VP3) store_v3(T, ot, r);
+                            else Vo[(ot * NT + T) * 64 + lane] = to_opnd(r);
                         }
                         else if (t < 2 * NC) Ko[(T * NC + ot) * 64 + lane] = to_opnd(r);
                         else Vo[(ot * NT + T) * 64 + lane] = to_opnd(r);
@@ -684,14 +705,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 f4 s[NT];
                 float m0 = -3.0e38f, m1 = -3.0e38f;
                 {
-                    u32x4 a0[2][3];
-                    u32x2 a2[2][3];
-                    k_load3(0, a0[0], a2[0]);
+                    // the next key tile's pieces in flight (two register sets) where the registers are there; the 20-tile form, which holds
+                    // three tiles' residual streams and q, reads a tile's pieces where it uses them (its SIMD partner covers the wait)
+                    constexpr int NB = VP3 ? 2 : 1;
+                    u32x4 a0[NB][3];
+                    u32x2 a2[NB][3];
+                    if (NB == 2) k_load3(0, a0[0], a2[0]);
 #pragma unroll
                     for (int J = 0; J < NT; ++J) {       // S^T tiles: rows = keys (A = K pieces), cols = queries (B = q pieces)
-                        if (J + 1 < NT) k_load3(J + 1, a0[(J + 1) & 1], a2[(J + 1) & 1]);
+                        if (NB == 2 && J + 1 < NT) k_load3(J + 1, a0[(J + 1) % NB], a2[(J + 1) % NB]);
+                        if (NB == 1) k_load3(J, a0[0], a2[0]);
                         __builtin_amdgcn_sched_barrier(0);
-                        s[J] = tile48(std::false_type{}, a0[J & 1], a2[J & 1], qb, qc, splat4(0.f));
+                        s[J] = tile48(std::false_type{}, a0[J % NB], a2[J % NB], qb, qc, splat4(0.f));
                         m0 = fmaxf(fmaxf(m0, s[J].x), s[J].y);
                         m1 = fmaxf(fmaxf(m1, s[J].z), s[J].w);
                     }
@@ -700,72 +725,100 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 const float m = quad_max(fmaxf(m0, m1));
                 const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m * SCALE_LOG2E, -m * SCALE_LOG2E};
                 f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
-                u32x4 pb[VP_PAIRS > 0 ? VP_PAIRS : 1][3];      // P^T as pieces: key-chunk pairs ...
-                u32x2 po[3], plo[3];                            // ... the odd last chunk; a pair's first chunk
-                // one key-chunk pair's V^T pieces (three feature tiles: 36 registers) at a time; the first pair's are requested in front
-                // of the exponentials
-                u32x4 v[NC][3];
-                auto v_load3 = [&](int pp) {
-#pragma unroll
-                    for (int t = 0; t < NC; ++t)
-#pragma unroll
-                        for (int pc = 0; pc < 3; ++pc) v[t][pc] = Vp3[t * VP_T16 + (pp * 3 + pc) * 64];
-                };
-                if (VP_PAIRS > 0) v_load3(0);
-#pragma unroll
-                for (int J = 0; J < NT; ++J) {
-                    const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
-                    const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
-                    const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-                    const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
-                    d0 += ea;
-                    d1 += ec;
-                    u32x2 pj[3];
-                    vt3::split3(f4{ea.x, ea.y, ec.x, ec.y}, pj[0], pj[1], pj[2]);
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) {
-                        if ((NT & 1) && J == NT - 1) po[pc] = pj[pc];
-                        else if (J & 1) pb[J >> 1][pc] = u32x4{plo[pc].x, plo[pc].y, pj[pc].x, pj[pc].y};
-                        else plo[pc] = pj[pc];
-                    }
-                }
-                const f2 dd = d0 + d1;
-                const float rden = __builtin_amdgcn_rcpf(quad_sum(dd.x + dd.y));     // v_rcp_f32: 1 ulp
-                fstamp();
-                f4 oA[NC], oB[NC];
-#pragma unroll
-                for (int t = 0; t < NC; ++t) oA[t] = oB[t] = splat4(0.f);
-                u32x2 vh[NC][3];
-                if (NT & 1) {
-#pragma unroll
-                    for (int t = 0; t < NC; ++t)
-#pragma unroll
-                        for (int pc = 0; pc < 3; ++pc) vh[t][pc] = Vp3h[t * VP_T16 * 2 + pc * 64];
-                }
-#pragma unroll
-                for (int pp = 0; pp < VP_PAIRS; ++pp) {        // O^T = V^T P^T: 3 feature-tile chains share B = a pair's P pieces
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 6; ++e)
-#pragma unroll
-                        for (int t = 0; t < NC; ++t) oA[t] = vt3::mma(v[t][TW[e]], pb[pp][TX[e]], oA[t]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (pp + 1 < VP_PAIRS) v_load3(pp + 1);
-                }
-                // proj's pieces of the first output tile, requested under the last MFMAs of P.V
+                f4 o[NC];
+                // proj's pieces of the first output tile are requested under the last MFMAs of P.V
                 u32x4 wa0[2][3];
                 u32x2 wa2[2][3];
-                wp_load3(0, wa0[0], wa2[0]);
-                if (NT & 1) {
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VP3) {
+                    u32x4 pb[VP_PAIRS > 0 ? VP_PAIRS : 1][3];      // P^T as pieces: key-chunk pairs ...
+                    u32x2 po[3], plo[3];                            // ... the odd last chunk; a pair's first chunk
+                    // one key-chunk pair's V^T pieces (three feature tiles: 36 registers) at a time; the first pair's are requested in front
+                    // of the exponentials
+                    u32x4 v[NC][3];
+                    auto v_load3 = [&](int pp) {
 #pragma unroll
-                    for (int e = 0; e < 6; ++e)
+                        for (int t = 0; t < NC; ++t)
 #pragma unroll
-                        for (int t = 0; t < NC; ++t) oB[t] = vt3::mma16(vh[t][TW[e]], po[TX[e]], oB[t]);
+                            for (int pc = 0; pc < 3; ++pc) v[t][pc] = Vp3[t * VP_T16 + (pp * 3 + pc) * 64];
+                    };
+                    if (VP_PAIRS > 0) v_load3(0);
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) {
+                        const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
+                        const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
+                        const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                        const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                        d0 += ea;
+                        d1 += ec;
+                        u32x2 pj[3];
+                        vt3::split3(f4{ea.x, ea.y, ec.x, ec.y}, pj[0], pj[1], pj[2]);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            if ((NT & 1) && J == NT - 1) po[pc] = pj[pc];
+                            else if (J & 1) pb[J >> 1][pc] = u32x4{plo[pc].x, plo[pc].y, pj[pc].x, pj[pc].y};
+                            else plo[pc] = pj[pc];
+                        }
+                    }
+                    const f2 dd = d0 + d1;
+                    const float rden = __builtin_amdgcn_rcpf(quad_sum(dd.x + dd.y));     // v_rcp_f32: 1 ulp
+                    fstamp();
+                    f4 oA[NC], oB[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) oA[t] = oB[t] = splat4(0.f);
+                    u32x2 vh[NC][3];
+                    if (NT & 1) {
+#pragma unroll
+                        for (int t = 0; t < NC; ++t)
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) vh[t][pc] = Vp3h[t * VP_T16 * 2 + pc * 64];
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < VP_PAIRS; ++pp) {        // O^T = V^T P^T: 3 feature-tile chains share B = a pair's P pieces
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) oA[t] = vt3::mma(v[t][TW[e]], pb[pp][TX[e]], oA[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pp + 1 < VP_PAIRS) v_load3(pp + 1);
+                    }
+                    wp_load3(0, wa0[0], wa2[0]);
+                    if (NT & 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) oB[t] = vt3::mma16(vh[t][TW[e]], po[TX[e]], oB[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = (oA[t] + oB[t]) * splat4(rden);
+                } else {
+                    // V^T stays an fp32 image (G256: no LDS for its pieces): exponentials in place, O^T = V^T P^T on fp32 MFMAs
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) {
+                        const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
+                        const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
+                        const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                        const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                        s[J] = f4{ea.x, ea.y, ec.x, ec.y};
+                        d0 += ea;
+                        d1 += ec;
+                    }
+                    const f2 dd = d0 + d1;
+                    const float rden = __builtin_amdgcn_rcpf(quad_sum(dd.x + dd.y));
+                    fstamp();
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = splat4(0.f);
+                    gemm_stage<NT, NC, true, WLDS>(
+                        [&](int J, opnd (&a)[NC]) {
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) a[t] = Vo[(t * NT + J) * 64 + lane];
+                        },
+                        [&](int J) { return s[J]; }, o);
+                    wp_load3(0, wa0[0], wa2[0]);
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
                 }
-                f4 o[NC];
-#pragma unroll
-                for (int t = 0; t < NC; ++t) o[t] = (oA[t] + oB[t]) * splat4(rden);
                 fstamp();
                 u32x4 ob[3];
                 u32x2 oc[3];
@@ -775,6 +828,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     if (ot + 1 < NC) wp_load3(ot + 1, wa0[(ot + 1) & 1], wa2[(ot + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     x[i][ot] = tile48(std::false_type{}, wa0[ot & 1], wa2[ot & 1], ob, oc, x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else if (!A3 && VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
                 // softmax((q k^T) * scale) (attn.py:40-41) as exp2(raw * (scale log2 e) - max_raw * (scale log2 e)): the scale, the
