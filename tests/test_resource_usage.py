@@ -22,7 +22,7 @@ DEFAULT_VIT48 = [
     (r"vts::stem_fused_kernel<[012], false, true>", 128),            # 1024 threads
     (r"vts::stem_stream_kernel<256, 128, [012]>", 128),
     (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), true, (false|true)>", 256),       # 512 threads; last flag: A3 (round 5)
-    (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true, false>", 256),
+    (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true, false>", 256),       # VT_BLOCKS_BF3=1
     (r"vth3::head_fused3_kernel", 168),                              # 768 threads
     (r"vth3::head_seq3_kernel<8, 2, false>", 256),
     # small batches / the plugin's one-sequence step
@@ -38,6 +38,11 @@ DEFAULT_VIT48 = [
 # vts::stem_a2_kernel reports ScratchSize 36 with VGPRs Spill 0 and not one scratch instruction: SGPRs spilled to VGPR lanes reserve a
 # frame that is never touched.  It must stay free of VGPR spills.
 SGPR_FRAME_ONLY = [r"vts::stem_a2_kernel"]
+# The G256 block kernel with K as pieces (VT_BLOCKS_BF3=2, the default; round 5) parks the q of a wave's second and third token tile
+# (6 float4) and one residual chunk in scratch across the qkv barrier and reloads each once where that tile's attention starts --
+# seven 16-byte stores + loads per block and wave, outside every loop (the 20-tile form holds three tiles' residual streams and q
+# at the 256-register cap).  Bounded so it cannot grow.
+PARKED = {r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true, true>": (64, 128)}      # (VGPRs spilled incl. SGPR-spill lanes, scratch bytes)
 # the f16 build (BASELINE config 5, -DVT_F16=1): the kernels its default path launches at B = 256 (round 4 advisor: they were printed
 # in the table but never gated)
 DEFAULT_F16 = [
@@ -70,6 +75,10 @@ def test_default_vit48_kernels_have_no_scratch_and_fit_their_register_cap(tables
 
 def test_no_vit48_kernel_spills_vector_registers(tables):
     for r in tables["vittrack"]:
+        bound = next((b for p, b in PARKED.items() if re.fullmatch(p, r["name"])), None)
+        if bound is not None:
+            assert r["vspill"] <= bound[0] and r["scratch"] <= bound[1], (r["name"], r, bound)
+            continue
         assert r["vspill"] == 0, (r["name"], r)
         if r["scratch"]:
             assert any(re.fullmatch(p, r["name"]) for p in SGPR_FRAME_ONLY), (r["name"], r)

@@ -726,9 +726,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 const f2 k2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m * SCALE_LOG2E, -m * SCALE_LOG2E};
                 f2 d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
                 f4 o[NC];
-                // proj's pieces of the first output tile are requested under the last MFMAs of P.V
-                u32x4 wa0[2][3];
-                u32x2 wa2[2][3];
+                // proj's pieces of the first output tile are requested under the last MFMAs of P.V (VP3; the 20-tile form reads them where
+                // it uses them, one register set)
+                constexpr int NWB = VP3 ? 2 : 1;
+                u32x4 wa0[NWB][3];
+                u32x2 wa2[NWB][3];
                 if constexpr (VP3) {
                     u32x4 pb[VP_PAIRS > 0 ? VP_PAIRS : 1][3];      // P^T as pieces: key-chunk pairs ...
                     u32x2 po[3], plo[3];                            // ... the odd last chunk; a pair's first chunk
@@ -815,7 +817,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                             for (int t = 0; t < NC; ++t) a[t] = Vo[(t * NT + J) * 64 + lane];
                         },
                         [&](int J) { return s[J]; }, o);
-                    wp_load3(0, wa0[0], wa2[0]);
 #pragma unroll
                     for (int t = 0; t < NC; ++t) o[t] = o[t] * splat4(rden);
                 }
@@ -825,9 +826,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 split_h3(o, ob, oc);
 #pragma unroll
                 for (int ot = 0; ot < NC; ++ot) {
-                    if (ot + 1 < NC) wp_load3(ot + 1, wa0[(ot + 1) & 1], wa2[(ot + 1) & 1]);
+                    if (NWB == 2 && ot + 1 < NC) wp_load3(ot + 1, wa0[(ot + 1) % NWB], wa2[(ot + 1) % NWB]);
+                    if (NWB == 1) wp_load3(ot, wa0[0], wa2[0]);
                     __builtin_amdgcn_sched_barrier(0);
-                    x[i][ot] = tile48(std::false_type{}, wa0[ot & 1], wa2[ot & 1], ob, oc, x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q));
+                    x[i][ot] = tile48(std::false_type{}, wa0[ot % NWB], wa2[ot % NWB], ob, oc, x[i][ot] + ld4(S + S_BPROJ + 16 * ot + 4 * q));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else if (!A3 && VT_BLK_OWNERS && T < NOWN && T != dbg_skip_tile && !(last_skip_z && 16 * T < len_z)) {
