@@ -56,7 +56,10 @@ VARIANTS = {
     "head_bf16x3_fused_form": {"VT_HEAD_BF3": "1", "VT_HEAD_FUSED": "1"},
     "head_fp32_mfma_small_batch_form": {"VT_HEAD_BF3": "0"},
     "head_fp32_mfma_fused_form": {"VT_HEAD_BF3": "0", "VT_HEAD_FUSED": "1"},
-    # the G128 frame form's MLP on fp32 MFMAs (the default multiplies exact three-piece bf16 splits: vt_blocks.h BF3, vt_bf3.h)
+    # the frame-form block kernels' three levels (vt_blocks.h, vt_bf3.h): 2 (default) = every contraction of the G128 form / qkv, MLP, q k^T
+    # and proj of the G256 form multiply exact three-piece bf16 splits (round 5: K, V^T published as pieces); 1 = qkv + MLP only
+    # (round 4); 0 = fp32 MFMAs.  Level 2 is what "large_batch_forms_forced" runs.
+    "blocks_qkv_mlp_only_bf16x3": {"VT_BLOCKS_BF3": "1", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
     "blocks_mlp_fp32_mfma": {"VT_BLOCKS_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
     # layer 3 of the fused G128 stem on fp32 MFMAs (the default multiplies exact three-piece bf16 splits there too)
     "stem_fused_layer3_fp32_mfma": {"VT_STEM_BF3": "0", "VT_STEM_FUSED": "1", "VT_HEAD_FUSED": "1", "VT_BLOCKS_TILE": "0"},
