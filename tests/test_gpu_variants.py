@@ -153,6 +153,16 @@ def test_vitb_graph_chains_match_eager(chains):
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
 
 
+def test_vitb_default_two_full_grid_chains_match_eager():
+    """Round 5 default: a captured ViT-Base step of >= 64 frames runs as two chains of half the frames, each chain's persistent GEMMs on
+    a workgroup per CU (they fill each other's partly empty last tile rounds).  B = 72 (two chains of 36) and B = 63 (one chain) must
+    both replay the eager step bit for bit."""
+    code = VITB_CHAINS_CODE.replace("for B in (5, 24):", "for B in (72, 63):")
+    env = {k: v for k, v in os.environ.items() if k not in ("VT_GRAPH_CHAINS", "VT_CHAIN_CUS", "VT_CHAIN_DELAY_US")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+
+
 # The bf16-split forms (vt_bf3.h: qkv + MLP of the frame-form block kernels, the F = 8 head's towers) multiply the same fp32 operands
 # as the fp32-MFMA forms they replace; on a full batch of random crops -- every frame-form kernel, 256 frames instead of a fixture's
 # 2-5 -- the two must agree to the fp32 noise floor of the net (a few 1e-6 on the maps), far inside the 1e-4 / 1e-5 the golden

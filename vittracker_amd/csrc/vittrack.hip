@@ -945,8 +945,12 @@ int create_vitb(const vt_config* cfg, vt_model** out) {
     A(m->pred, B * 4); A(m->hann, B * 4); A(m->conf, B);
     if (!rc) rc = upload(m->window, hann2d(m->F));
     if (!rc && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(VT_ERR_HIP, "hipStreamCreate failed");
-    // graph chains (vt_graph_capture_steps): frame slices of one step as concurrent chains, each on its share of the CUs
-    m->graph_chains = env_int("VT_GRAPH_CHAINS", 1);
+    // graph chains (vt_graph_capture_steps): frame slices of one step as concurrent chains.  Default (round 5; 0 = auto): a captured step
+    // of >= 64 frames runs as TWO chains of half the frames whose persistent GEMMs each launch a workgroup per CU -- the chains' kernels
+    // then fill each other's last, partly empty tile rounds (3.75 of 4, 7.5 of 8 at B = 256) and ramps: 17.63 -> 16.88 ms per step at
+    // B = 256 (tools/gpu_vbchains.sh; each chain on HALF the CUs instead: 17.66, i.e. nothing -- NOTES R5-6).  Frames are independent:
+    // outputs are bit-identical to the one-chain step (tests/test_gpu_variants.py).
+    m->graph_chains = env_int("VT_GRAPH_CHAINS", 0);
     m->chain_cus = env_int("VT_CHAIN_CUS", 0);
     m->chain_delay_us = env_int("VT_CHAIN_DELAY_US", 0);
     for (int i = 0; i < 3 && !rc; ++i)
@@ -1611,7 +1615,7 @@ static int forward_slice(vt_model* m, const float* z, const float* x, size_t f0,
     if (m->vb) {   // ViT-Base: the chains' persistent GEMMs split the CUs between them
         int ncu = 256;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
-        const vb::Slice sl{f0, Btot, m->chain_cus > 0 ? m->chain_cus : ncu / nch};
+        const vb::Slice sl{f0, Btot, m->chain_cus > 0 ? m->chain_cus : (m->graph_chains == 0 ? ncu : ncu / nch)};
         std::string err;
         int rc;
         if ((rc = vb::stem(m->vb, z + f0 * 3 * Tz * Tz, x + f0 * 3 * Tx * Tx, nb, st, nullptr, &err, &sl))) return fail(rc, err);
@@ -1635,7 +1639,8 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
     // One step may be captured as NCH independent chains over frame slices (fork / join with events):
     // the kernels of one slice can then overlap the kernels of the others.  Measured slower with the
     // one-workgroup-per-frame kernels (large LDS: no two workgroups share a CU): 107.7 -> 132 us with 2 chains.
-    int nch = m->graph_chains;   // default 1
+    int nch = m->graph_chains;   // vit_48: default 1; ViT-Base: 0 = auto (two chains from 64 frames up, create_vitb)
+    if (nch == 0) nch = (m->vb && B >= 64) ? 2 : 1;
     nch = (nsteps > 1 || !z_dev || !z_dev[0]) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
