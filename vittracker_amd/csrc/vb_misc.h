@@ -99,18 +99,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // Per-row rstd from the (sum, centred sum of squares) pairs the residual-writing GEMM epilogues leave per 64-column wave slice
 // (vb_gemm.h): Chan's pairwise update, exact mean first.  stats: [P][ld] float2, P = C / 64.  One thread per row.
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restrict__ stats, int P, int ld, int M, float eps,
-                                                          float* __restrict__ rstd) {
+template <int P>
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restrict__ stats, int ld, int M, float eps, float* __restrict__ rstd) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
+    vbg::f2 v[P];           // all P pairs requested at once: one memory round trip per row
+#pragma unroll
+    for (int p = 0; p < P; ++p) v[p] = stats[(size_t)p * ld + m];
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += stats[(size_t)p * ld + m].x;
+#pragma unroll
+    for (int p = 0; p < P; ++p) s += v[p].x;
     const float inv_c = 1.0f / (64.0f * P), mean = s * inv_c;
     float m2 = 0.f;
+#pragma unroll
     for (int p = 0; p < P; ++p) {
-        const vbg::f2 v = stats[(size_t)p * ld + m];
-        const float d = v.x * (1.0f / 64.0f) - mean;
-        m2 += v.y + 64.0f * d * d;
+        const float d = v[p].x * (1.0f / 64.0f) - mean;
+        m2 += v[p].y + 64.0f * d * d;
     }
     rstd[m] = 1.0f / sqrtf(m2 * inv_c + eps);
 }

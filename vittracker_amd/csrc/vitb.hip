@@ -165,8 +165,8 @@ int run_layernorm(const float* resid, const float* g, const float* b, int B, hip
 constexpr int STAT_P = C / 64;       // (sum, M2) pairs per residual row: one per 64-column wave slice of the 256-wide GEMM tiles
 
 int run_finalize(const VbModel* m, size_t r0, int M, hipStream_t st, const Err& E) {
-    hipLaunchKernelGGL(vbm::ln_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, st, m->stats.p + r0, STAT_P, (int)(m->stats.n / STAT_P), M,
-                       LN_EPS, m->rstd.p + r0);
+    hipLaunchKernelGGL(vbm::ln_finalize_kernel<STAT_P>, dim3((M + 255) / 256), dim3(256), 0, st, m->stats.p + r0, (int)(m->stats.n / STAT_P), M, LN_EPS,
+                       m->rstd.p + r0);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }
