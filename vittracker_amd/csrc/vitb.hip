@@ -307,7 +307,10 @@ int load_weights(VbModel* m, const TensorMap& tm, std::string* err) {
     const char* towers[3] = {"ctr", "offset", "size"};
     for (int li = 0; li < 4; ++li) {
         const int cin = HEAD_CH[li], cout = HEAD_CH[li + 1], K = 9 * cin;
-        const int rows = li == 0 ? cout : (cout < 64 ? 64 : cout);           // conv2..4 run with BN = 64: pad rows to 64
+        // conv1: towers along N.  conv2 (N = 128 per tower, K = 2304) runs on the 256 x 256 software-pipelined tile, one group per tower, with
+        // its weight rows zero-padded to 256 (half of every MFMA column block is padding, and it still beats the two-buffer 256 x 64 loop:
+        // 268 -> ~180 us, round 5); conv3 / conv4 keep the narrow tile (BN = 64: rows padded to 64)
+        const int rows = li == 0 ? cout : (li == 1 ? 256 : (cout < 64 ? 64 : cout));
         std::vector<float> w((size_t)3 * rows * K, 0.f), bias((size_t)3 * cout);
         for (int t = 0; t < 3; ++t) {
             const std::string cn = std::string("box_head.conv") + std::to_string(li + 1) + "_" + towers[t];
@@ -471,13 +474,14 @@ int head(VbModel* m, const float* feat_in, int B, hipStream_t st, float* score, 
     bf16* maps[4] = {m->map1.p + f0 * (size_t)P2 * HEAD_CH[1], m->map2.p + f0 * (size_t)P2 * HEAD_CH[2],
                      m->map3.p + f0 * (size_t)P2 * HEAD_CH[3], m->t4.p + f0 * (size_t)LX * HEAD_CH[4]};
     for (int li = 1; li < 4; ++li) {   // conv2..4: one launch per layer, blockIdx.y = tower
-        const int cin = HEAD_CH[li], cout = HEAD_CH[li + 1], rows = cout < 64 ? 64 : cout;
+        const int cin = HEAD_CH[li], cout = HEAD_CH[li + 1], rows = li == 1 ? 256 : (cout < 64 ? 64 : cout);
         vbg::Args a{};
         a.X = maps[li - 1]; a.W = m->wc[li].p; a.bias = m->bc[li].p; a.out = maps[li];
         a.M = M; a.N = cout; a.K = 9 * cin; a.ldo = cout; a.C = cin; a.F = F; a.out_padded = li < 3;
         a.gX = Bt * P2 * cin; a.gW = (long long)rows * 9 * cin; a.gBias = cout;
         a.gOut = li < 3 ? Bt * P2 * cout : Bt * LX * cout;
-        if ((rc = launch_gemm<256, 64, 8, 1, vbg::A_CONV, vbg::EPI_CONV>(a, 3, st, E, cus))) return rc;
+        if (li == 1 ? (rc = launch_gemm<256, 256, 2, 4, vbg::A_CONV, vbg::EPI_CONV>(a, 3, st, E, cus))
+                    : (rc = launch_gemm<256, 64, 8, 1, vbg::A_CONV, vbg::EPI_CONV>(a, 3, st, E, cus))) return rc;
     }
     hipLaunchKernelGGL((vbm::conv5_kernel<32>), dim3((M + 255) / 256), dim3(256), 0, st, maps[3], m->w5.p, m->b5.p, M, LX,
                        (size_t)(Bt * LX * HEAD_CH[4]), score, size, offset);
