@@ -12,6 +12,7 @@
 #include "vb_attn.h"
 #include "vb_gemm.h"
 #include "vb_misc.h"
+#include "vb_qkvattn.h"
 
 using vbg::bf16;
 
@@ -68,6 +69,7 @@ struct VbModel {
     // LayerNorm folded into qkv / fc1 (vb_gemm.h): xn then holds the RAW residual rows in bf16, written by the GEMM epilogues that
     // produce them, rstd their 1 / sqrt(var + eps), stats the epilogues' per-slice (sum, M2) pairs [C / 64][max rows]
     bool fold = true;
+    bool fused_qkv = true;          // VB_FUSED_QKV: the qkv projection inside the attention kernel (vb_qkvattn.h) instead of qk GEMM + v GEMM + attention
     Buf<float> rstd;
     Buf<vbg::f2> stats;
 };
@@ -201,6 +203,7 @@ int create(const vt_config* cfg, VbModel** out, std::string* err) {
     m->maxB = cfg->max_batch;
     m->blk.resize(m->depth);
     m->fold = env_int("VB_LN_FOLD", 1) != 0;
+    m->fused_qkv = env_int("VB_FUSED_QKV", 1) != 0;
     const size_t B = (size_t)cfg->max_batch, M = B * L, P2 = (size_t)(F + 2) * (F + 2);
     hipError_t e = hipSuccess;
     auto A = [&](auto& buf, size_t n) { if (e == hipSuccess) e = buf.alloc(n); };
@@ -222,6 +225,7 @@ int create(const vt_config* cfg, VbModel** out, std::string* err) {
     if (e == hipSuccess) e = allow_lds(gemm_kernel<256, 256, 2, 4, A_CONV, EPI_CONV>, lds_bytes<256, 256>());
     if (e == hipSuccess) e = allow_lds(gemm_kernel<256, 64, 8, 1, A_CONV, EPI_CONV>, lds_bytes<256, 64>());
     if (e == hipSuccess) e = allow_lds(vba::attn_kernel<L, HD>, vba::Geo<L, HD>::LDS_BYTES);
+    if (e == hipSuccess) e = allow_lds(vbq::qkv_attn_kernel, vbq::LDS_BYTES);
     if (e != hipSuccess) {
         destroy(m);
         return E.fail(VT_ERR_HIP, std::string("ViT-Base workspace: ") + hipGetErrorString(e));
@@ -415,6 +419,13 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
     for (int i = 0; i < nblocks; ++i) {
         const BlockW& b = m->blk[i];
         if (!fold && (rc = run_layernorm(resid, b.ln1g.p, b.ln1b.p, B, st, xn, nullptr, nullptr, E))) return rc;
+        if (m->fused_qkv) {          // projection + attention of a (frame, head) in one workgroup: q / k / v^T never leave the CU
+            vbq::Args qa{};
+            qa.X = xn; qa.W = b.wqkv.p; qa.bias = b.bqkv.p; qa.rstd = rstd; qa.out = ao; qa.B = B; qa.heads = HEADS;
+            const int grid = std::max(8, (cus > 0 ? std::min(cus, num_cus()) : num_cus()) / 8 * 8);
+            hipLaunchKernelGGL(vbq::qkv_attn_kernel, dim3(grid), dim3(512), vbq::LDS_BYTES, st, qa);
+            VB_HIP(hipGetLastError());
+        } else {
         vbg::Args a{};
         a.rstd = rstd;
         a.X = xn; a.W = b.wqkv.p; a.bias = b.bqkv.p; a.out = qk;          // q | k: rows 0 .. 2C of W_qkv
@@ -427,6 +438,7 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
         constexpr int attn_lds = vba::Geo<L, HD>::LDS_BYTES;
         hipLaunchKernelGGL((vba::attn_kernel<L, HD>), dim3(B * HEADS), dim3(256), attn_lds, st, qk, vt, ao, HEADS);
         VB_HIP(hipGetLastError());
+        }
         vbg::Args p{};
         p.X = ao; p.W = b.wproj.p; p.bias = b.bproj.p; p.resid = resid; p.M = M; p.N = C; p.K = C;
         if (fold) { p.xb = xn; p.stats = stats; p.ldstats = ldstats; }
