@@ -2,6 +2,7 @@
 # Collect hardware counters for one bench.py configuration, one rocprofv3 --pmc pass per counter
 # set (counters only: no trace domains, as the GPU pool requires).  Usage:
 #   tools/pmc.sh <outdir> [bench.py args...]
+#   PMC_VITB=1 tools/pmc.sh <outdir> [frames]      the same passes over tools/vitb_time.py (the captured ViT-Base step)
 set -u
 OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -16,7 +17,11 @@ SETS=(
 )
 i=0
 for s in "${SETS[@]}"; do
-  timeout 300 rocprofv3 --pmc $s --output-format csv -d "$R/$OUT/set$i" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-extra --streams 1 "$@" > "$R/$OUT/set$i.log" 2>&1
+  if [ -n "${PMC_VITB:-}" ]; then
+    timeout 300 rocprofv3 --pmc $s --output-format csv -d "$R/$OUT/set$i" -- python3 "$R/tools/vitb_time.py" "$@" > "$R/$OUT/set$i.log" 2>&1
+  else
+    timeout 300 rocprofv3 --pmc $s --output-format csv -d "$R/$OUT/set$i" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu --no-extra --streams 1 "$@" > "$R/$OUT/set$i.log" 2>&1
+  fi
   i=$((i+1))
 done
 python3 "$R/tools/pmc_summary.py" "$R/$OUT" | tee "$R/$OUT/summary.txt"

@@ -20,8 +20,10 @@
 #pragma once
 #include "vb_gemm.h"
 
-#ifndef VB_QA_SWP
-#define VB_QA_SWP 1         // 1: software-pipelined k-loop (DMA of k-tile t + 2 under the MFMAs of t); 0: the simple two-buffer loop
+#ifndef VB_QA_DBG
+#define VB_QA_DBG 0         // timing experiments only (wrong results): 1 = projection + epilogue only (no attention), 2 = attention only (no k-loop),
+                            // 3 / 4 / 5 = mode 1 with every W / X / W and X piece fetched from k-tile 0 of head 0 / frame 0 (L2 hits: what the fill costs),
+                            // 6 = mode 1 without the DMAs (stale LDS), 7 = mode 1 without fragment reads and MFMAs (the fill alone)
 #endif
 
 namespace vbq {
@@ -46,6 +48,7 @@ struct Args {
     const float* rstd;    // [B L] or null
     bf16* out;            // [B L][DM] attention output (head h at columns h HD ..)
     int B, heads;
+    int hgroup;           // heads walked together (see the item order in the kernel); divides heads
 };
 
 __global__ __launch_bounds__(512) void qkv_attn_kernel(const Args a) {
@@ -57,28 +60,21 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const Args a) {
     char* const Vimg = smem + 2 * IMG_BYTES;
 
     // ---- items: XCD x (blocks with blockIdx % 8 == x share an L2) owns frames x, x + 8, ...; its workgroups walk (frame, head) pairs
-    // frame-major, so the heads of a frame run at about the same time on one XCD and share the fetch of its rows
+    // frame-major inside a GROUP of a.hgroup heads, group after group: the heads of a frame run at about the same time on one XCD and
+    // share the fetch of its rows, and a group's weight rows (hgroup x 288 KiB) stay nearer than a whole qkv matrix (3.4 MiB against the
+    // 4 MiB L2 the frames stream through).  Measured at 256 frames: groups of 12 / 6 / 4 / 3 / 2 / 1 heads 379.9 / 372.5 / 375.4 / 374.7 /
+    // 383.0 / 459.2 us per launch -- the order hardly matters until every CU of an XCD reads different rows (VB_QA_HGROUP, default 6)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
     const int nfx = (a.B - xcd + 7) / 8;                     // frames of this XCD
     const int nitems = nfx * a.heads;
 
-    // ---- DMA sources of this wave's 8 pieces per k-tile: per-lane BYTE offsets from the item's (wave-uniform) X / W bases
-    unsigned soff[8];
-    {
-        const int drow = lane_k >> 3, dk = ((lane_k & 7) ^ drow) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = w + 8 * i;
-            if (p < XP) soff[i] = (unsigned)((p * 8 + drow) * DM + dk) * 2u;
-            else {
-                const int pw = p - XP, blk = pw >> 3, rr = (pw & 7) * 8 + drow;
-                soff[i] = (unsigned)((blk * DM + rr) * DM + dk) * 2u;            // + the head's h HD rows, in the base
-            }
-        }
-    }
+    // ---- DMA sources of this wave's 8 pieces per k-tile (piece p = w + 8 i: i < 5 X rows p 8 .., i >= 5 the W rows (w 8 ..) of q / k / v):
+    // every piece reads row (w 8 + lane / 8) of ITS 64-row block at the lane's swizzled k offset, so ONE per-lane byte offset serves all
+    // eight; what differs per piece is wave-uniform and goes into the scalar base
+    const unsigned soff = (unsigned)((w * 8 + (lane_k >> 3)) * DM + (((lane_k & 7) ^ (lane_k >> 3)) * 8)) * 2u;
 
     for (int li = slot; li < nitems; li += per) {
-        const int lf = li / a.heads, h = li - lf * a.heads, f = xcd + 8 * lf;
+        const int gsz = nfx * a.hgroup, hg = li / gsz, rem = li - hg * gsz, lf = rem / a.hgroup, h = hg * a.hgroup + rem - lf * a.hgroup, f = xcd + 8 * lf;
         // Every per-lane address of an item comes from a FRESH opaque copy of the lane index: as invariants of the item loop hipcc
         // computes dozens of them up front and spills them around the k-loop (the first build: 464 B of scratch per lane)
         int lane = lane_k;
@@ -86,18 +82,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const Args a) {
         const int q = lane >> 4;
         const unsigned long long xb64 = reinterpret_cast<unsigned long long>(a.X + (size_t)f * L * DM);
         const unsigned long long wb64 = reinterpret_cast<unsigned long long>(a.W + (size_t)h * HD * DM);
-        auto issue = [&](int kt, int stg) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int p = w + 8 * i;
-                const unsigned long long b64 = (p < XP ? xb64 : wb64) + (unsigned long long)kt * 128ull;
-                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
-                const char* base = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-                unsigned off = soff[i];
-                asm volatile("" : "+v"(off));
-                glds16(base + (size_t)off, smem + stg * STAGE_BYTES + p * 1024);
-            }
-        };
         // fragment addresses: one opaque base register per (operand, stage, k-step) + an immediate per tile
         int fxa[2][2], fwa[2][2];
         {
@@ -118,45 +102,94 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const Args a) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) acc[i][j] = splat4(0.f);
         // this wave's feature tile i: kind i >> 1 (0 q, 1 k, 2 v), tile (i >> 1) 4 + wn 2 + (i & 1) of the head's 12
-        auto kstep = [&](auto stg, int kk) {
-            constexpr int ST = decltype(stg)::value;
-            bf16x8 fx[5], fw[6];
-            const char* xp = smem + fxa[ST][kk];
-            const char* wp = smem + fwa[ST][kk];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) fx[j] = *reinterpret_cast<const bf16x8*>(xp + j * 2048);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(wp + ((i >> 1) * 4 + (i & 1)) * 2048);
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    if (i >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw[i], acc[i][j], 0, 0, 0);     // v: tokens on rows
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
-                }
-        };
         constexpr int NK = DM / 64;
         static_assert(NK % 2 == 0, "k-tiles come in stage pairs");
         const std::integral_constant<int, 0> S0{};
         const std::integral_constant<int, 1> S1{};
-        auto ktile = [&](auto stg) {
-            kstep(stg, 0);
-            kstep(stg, 1);
+        auto SB = [&]() { __builtin_amdgcn_sched_barrier(0); };
+        // ---- projection k-loop, software-pipelined; k-tile t lives in stage t & 1.  A k-tile is 12 GROUPS of 5 MFMAs: group g of half
+        // H0 (k-step 0) / H1 (k-step 1) multiplies the wave's feature tile g with its five token tiles.  Registers: both k-steps' token
+        // fragments (XA: k-step 0, XB: k-step 1) and a ROLLING window of three weight fragments (the stream (t, k0, 0..5), (t, k1, 0..5),
+        // (t + 1, k0, 0..5) ...; element e + 2 is requested in group e) -- with all four fragment sets resident (88 registers) the loop
+        // spilled its address registers and every reload drained the DMA queue (vmcnt).
+        //     H0(t)   groups 0-5 on XA        | reads XB <- tile t k-step 1, weight stream          | DMA: W pieces of tile t + 1 (3 per wave, L2-resident:
+        //                                                                                             they land within the half) -> other stage, groups 0-2
+        //     Bm(t)   vmcnt(0) lgkmcnt(0), barrier: tile t + 1 has landed (its X pieces were issued a whole k-tile ago); this stage's X region is in registers
+        //     H1(t)   groups 0-5 on XB        | reads XA <- tile t + 1 k-step 0, weight stream      | DMA: X pieces of tile t + 2 (5 per wave) -> this
+        //                                                                                             stage's X region, groups 0-4
+        //     Be(t)   lgkmcnt(0), barrier: this stage's W region is in registers (the next half's W DMA may overwrite it)
+        // A region is written only behind the barrier that follows its last read; data is read only behind the barrier that follows the
+        // wait that retires its DMA.
+        auto dma = [&](int kt, int stg, int i) {                    // this wave's piece slot i (0-4: X, 5-7: W) of k-tile kt -> stage stg
+            const int p = w + 8 * i;
+            unsigned long long b64 = (i < 5 ? xb64 + (unsigned long long)i * (64ull * DM * 2) : wb64 + (unsigned long long)(i - 5) * ((unsigned long long)DM * DM * 2)) +
+                                           (unsigned long long)kt * 128ull;
+            if (VB_QA_DBG == 3 || VB_QA_DBG == 5) { if (i >= 5) b64 = reinterpret_cast<unsigned long long>(a.W) + (unsigned long long)(i - 5) * ((unsigned long long)DM * DM * 2); }
+            if (VB_QA_DBG == 4 || VB_QA_DBG == 5) { if (i < 5) b64 = reinterpret_cast<unsigned long long>(a.X) + (unsigned long long)i * (64ull * DM * 2); }
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b64), hi = __builtin_amdgcn_readfirstlane((unsigned)(b64 >> 32));
+            const char* base = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+            unsigned off = soff;
+            asm volatile("" : "+v"(off));
+            if (VB_QA_DBG != 6) glds16(base + (size_t)off, smem + stg * STAGE_BYTES + p * 1024);
         };
-        // ---- projection k-loop: two stages, the DMA of k-tile t + 1 under the MFMAs of t
-        issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < NK; kt += 2) {
-            issue(kt + 1, 1);
-            ktile(S0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 2 < NK) issue(kt + 2, 0);
-            ktile(S1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+        bf16x8 XA[5], XB[5], Wr[3];
+        auto ldx = [&](auto stg, int kk, int j) { return *reinterpret_cast<const bf16x8*>(smem + fxa[decltype(stg)::value][kk] + j * 2048); };
+        auto ldw = [&](auto stg, int kk, int i) { return *reinterpret_cast<const bf16x8*>(smem + fwa[decltype(stg)::value][kk] + ((i >> 1) * 4 + (i & 1)) * 2048); };
+        auto mma5 = [&](int i, const bf16x8 (&fx)[5], const bf16x8 fw) {
+            if (VB_QA_DBG == 7) return;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (i >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fw, acc[i][j], 0, 0, 0);     // v: tokens on rows
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fx[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        auto ktile = [&](int kt, auto stg) {
+            constexpr int ST = decltype(stg)::value;
+            const std::integral_constant<int, ST ^ 1> nstg{};
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {                 // H0: stream elements 0-5
+                Wr[(g + 2) % 3] = g + 2 < 6 ? ldw(stg, 0, g + 2) : ldw(stg, 1, g + 2 - 6);
+                if (g < 5) XB[g] = ldx(stg, 1, g);
+                if (g < 3 && kt + 1 < NK) dma(kt + 1, ST ^ 1, 5 + g);
+                SB();
+                mma5(g, XA, Wr[g % 3]);
+                SB();
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            SB();
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {                 // H1: stream elements 6-11
+                if (g + 2 < 6) Wr[(6 + g + 2) % 3] = ldw(stg, 1, g + 2);
+                else if (kt + 1 < NK) Wr[(6 + g + 2) % 3] = ldw(nstg, 0, g + 2 - 6);
+                if (g < 5 && kt + 1 < NK) XA[g] = ldx(nstg, 0, g);
+                if (g < 5 && kt + 2 < NK) dma(kt + 2, ST, g);
+                SB();
+                mma5(g, XB, Wr[(6 + g) % 3]);
+                SB();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            SB();
+        };
+        if (VB_QA_DBG != 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma(0, 0, i);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) dma(1, 1, i);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");         // tile 0 (8 pieces) has landed; tile 1's five X pieces stay in flight
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < 5; ++j) XA[j] = ldx(S0, 0, j);
+            Wr[0] = ldw(S0, 0, 0);
+            Wr[1] = ldw(S0, 0, 1);
+            for (int kt = 0; kt < NK; kt += 2) {
+                ktile(kt, S0);
+                ktile(kt + 1, S1);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
         // ---- epilogue: y = rstd * acc + bias, as bf16 into the attention's operand images (the stages are free: every wave has
         // passed the last k-tile's barrier)
         {
@@ -280,8 +313,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const Args a) {
                 for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<bf16x4*>(o + dt * 16) = vbg::to_bf16x4(O[u][dt] * splat4(inv[u]));
             }
         };
-        pass(std::integral_constant<int, 2>{}, w, w + 8);
-        if (w < 4) pass(std::integral_constant<int, 1>{}, w + 16, 0);
+        if (VB_QA_DBG != 1 && VB_QA_DBG < 3) {
+            pass(std::integral_constant<int, 2>{}, w, w + 8);
+            if (w < 4) pass(std::integral_constant<int, 1>{}, w + 16, 0);
+        }
         __syncthreads();             // the images are dead: the next item's staging may overwrite them
     }
 }

@@ -422,6 +422,7 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
         if (m->fused_qkv) {          // projection + attention of a (frame, head) in one workgroup: q / k / v^T never leave the CU
             vbq::Args qa{};
             qa.X = xn; qa.W = b.wqkv.p; qa.bias = b.bqkv.p; qa.rstd = rstd; qa.out = ao; qa.B = B; qa.heads = HEADS;
+            { static const int hgv = env_int("VB_QA_HGROUP", 6); qa.hgroup = (hgv > 0 && HEADS % hgv == 0) ? hgv : HEADS; }
             const int grid = std::max(8, (cus > 0 ? std::min(cus, num_cus()) : num_cus()) / 8 * 8);
             hipLaunchKernelGGL(vbq::qkv_attn_kernel, dim3(grid), dim3(512), vbq::LDS_BYTES, st, qa);
             VB_HIP(hipGetLastError());
