@@ -56,6 +56,9 @@
 #ifndef VB_SWP_NO_BARRIER
 #define VB_SWP_NO_BARRIER 0  // timing experiments only: no rendezvous per k-tile (races by design)
 #endif
+#ifndef VB_RESID_AHEAD
+#define VB_RESID_AHEAD 2      // residual-row groups (16 rows x 256 B per wave) requested ahead of their use in the RESID / PATCH epilogue
+#endif
 #ifndef VB_EPI_NT
 #define VB_EPI_NT 0          // 1: every epilogue's stores (and the residual's loads) carry the non-temporal hint (measured: +-0 except
 #endif                       //    the transposed V stores, which always carry it: v projection 100 -> 92 us)
@@ -312,21 +315,30 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             // f32 residual stream: chunk = 16 rows x 256 B; read-modify-write in whole rows, loads before stores.  Next to it
             // (LayerNorm folded into the next GEMM): the rows' bf16 copy and, per row, this wave's 64-column (sum, centred M2)
             const int tn = n0 / BN;
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-#pragma unroll
-                for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j] + bs[i];
-                f4 old[4];
-                const int ch = lane & 15, r0 = lane >> 4;
+            // the rows' old values (the position table for PATCH) are requested VB_RESID_AHEAD row groups ahead of their use: asked for
+            // where they are added, every one of a tile's TM row groups waits a whole memory latency per wave
+            constexpr int AH = VB_RESID_AHEAD;
+            f4 oldq[AH + 1][4];
+            const int ch = lane & 15, r0 = lane >> 4;
+            auto load_old = [&](int j, f4 (&o)[4]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int m = mw + j * 16 + 4 * t + r0;
                     const int mc = CHECK ? (m < a.M ? m : a.M - 1) : m;
                     if constexpr (EPI == EPI_RESID)
-                        old[t] = VB_EPI_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.resid + (size_t)mc * a.N + nw + ch * 4))
-                                           : ld4(a.resid + (size_t)mc * a.N + nw + ch * 4);
-                    else old[t] = ld4(a.pos + (size_t)(mc % a.L) * a.N + nw + ch * 4);
+                        o[t] = VB_EPI_NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.resid + (size_t)mc * a.N + nw + ch * 4))
+                                         : ld4(a.resid + (size_t)mc * a.N + nw + ch * 4);
+                    else o[t] = ld4(a.pos + (size_t)(mc % a.L) * a.N + nw + ch * 4);
                 }
+            };
+#pragma unroll
+            for (int j = 0; j < AH && j < TM; ++j) load_old(j, oldq[j]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j] + bs[i];
+                if (j + AH < TM) load_old(j + AH, oldq[(j + AH) % (AH + 1)]);
+                f4 (&old)[4] = oldq[j % (AH + 1)];
                 lds_fence();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
