@@ -23,6 +23,12 @@
 #include "vt_head.h"
 
 #ifndef VT_F16
+#ifndef VT_SEQ3_C2_MAXP
+#define VT_SEQ3_C2_MAXP 5     // head_seq3's conv2: chunk pairs (= taps) per weight pass and waves that work on it (SeqConvB)
+#endif
+#ifndef VT_SEQ3_C2_ACT
+#define VT_SEQ3_C2_ACT 8
+#endif
 #ifndef VT_H3_SKIP
 #define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs (head_seq3: no conv2), 4 = no weight loads in conv1's steady state,
                            // 8 = head_seq3: no conv3 / conv4, 16 = head_seq3: no activation reads in conv1's steady state
@@ -439,17 +445,27 @@ static_assert(SEQ3_LDS_BYTES <= 160 * 1024, "LDS");
 // icq and icq + 1: NPIX * 8 = 128 (mod 256) puts them in complementary bank halves
 static_assert((G16::NPIX * 8) % 256 == 128, "piece planes: conflict-free ds_read_b64");
 
-// conv1 (48 -> 32, 3 x 3) + bias + ReLU from the piece-planar input map to the fp32 map m1.  Work split as vth::HeadConv: wave ->
-// (output tile wave & 1, pixel tiles (wave >> 1) + NW / 2 * i).  Weights: the [ot][pair][piece][lane] image of head_fused3, in
-// register passes of MAXP chunk pairs, double-buffered.
-template <int NW, int MAXP>
-struct SeqConv1 {
-    static constexpr int NQ = C / 4, NCH = nchunks(C), NCP = npairs(C), TSTEP = NW / 2, NPT = G16::NT / TSTEP;
+// One 3 x 3 conv + bias + ReLU of the sequential head as three-piece products: conv1 (48 -> 32) from the input map's pieces, conv2
+// (32 -> 16) from conv1's output, which conv1's epilogue writes as pieces.  compute() leaves the ReLU'd results in registers; the
+// caller stores them (as pieces / as fp32) behind the barrier that protects the region they go to.  Work split: a 2-output-tile
+// layer gives wave -> (output tile wave & 1, pixel tiles (wave >> 1) + NW / 2 * i), a 1-tile layer pixel tiles wave + NW * i (a pixel
+// tile = one row of the 16 x 16 map).  Weights: the [ot][pair][piece][lane] images of head_fused3 (a chunk pair of conv2 = one tap's
+// 32 channels), in register passes of MAXP chunk pairs, double-buffered.
+// ACT: waves that work on a 1-output-tile layer (each then covers 16 / ACT pixel tiles per weight fragment it loads: the layer's weight
+// image is streamed once per ACTIVE wave, and that stream -- L1 -> registers at 64 B per cycle and CU -- is what bounds these layers).
+template <int CIN, int COUT, int NW, int MAXP_, int ACT = NW>
+struct SeqConvB {
+    static constexpr int NQ = CIN / 4, NCH = nchunks(CIN), NCP = npairs(CIN), NOT = ntiles(COUT);
+    static constexpr int TSTEP = NOT == 2 ? NW / 2 : ACT, NPT = G16::NT / TSTEP;
+    static constexpr int MAXP = NCP < MAXP_ ? NCP : MAXP_;
     static constexpr int NPASS = (NCP + MAXP - 1) / MAXP, LASTN = NCP - (NPASS - 1) * MAXP;
     static constexpr int PS_IN = NQ * G16::NPIX;
-    static_assert(NQ % 4 == 0 && G16::NT % TSTEP == 0, "a chunk never straddles two taps; pixel tiles divide over the waves");
+    static_assert(NQ % 4 == 0 && G16::NT % TSTEP == 0 && NOT >= 1 && NOT <= 2, "a chunk never straddles two taps; pixel tiles divide over the waves");
     u32x4 a[2][MAXP][3];
 
+    __device__ static __forceinline__ bool active(int wave) { return NOT == 2 || ACT == NW || wave < ACT; }
+    __device__ static __forceinline__ int ot_of(int wave) { return NOT == 2 ? (wave & 1) : 0; }
+    __device__ static __forceinline__ int tile_of(int wave, int i) { return (NOT == 2 ? (wave >> 1) : wave) + TSTEP * i; }
     __device__ __forceinline__ void load_pass(const u32x4* __restrict__ wb, int p0, int n, int lane, u32x4 (&dst)[MAXP][3]) {
 #pragma unroll
         for (int k = 0; k < MAXP; ++k)
@@ -459,17 +475,17 @@ struct SeqConv1 {
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void prefetch(const u32x4* __restrict__ wimg, int wave, int lane) {
-        load_pass(wimg + (size_t)(wave & 1) * NCP * 192, 0, MAXP, lane, a[0]);
+        if (active(wave)) load_pass(wimg + (size_t)ot_of(wave) * NCP * 192, 0, MAXP, lane, a[0]);
     }
-    __device__ __forceinline__ void run(const u32x2* in_map, f4* out_map, const u32x4* __restrict__ wimg,
-                                        const float* __restrict__ bias, int wave, int lane) {
-        const int q = lane >> 4, ot = wave & 1, tfirst = wave >> 1;
+    __device__ __forceinline__ void compute(const u32x2* in_map, const u32x4* __restrict__ wimg, const float* __restrict__ bias, int wave,
+                                            int lane, bool skip, f4 (&acc)[NPT]) {
+        const int q = lane >> 4, ot = ot_of(wave);
         const u32x4* __restrict__ wb = wimg + (size_t)ot * NCP * 192;
-        f4 acc[NPT];
         const f4 bv = ld4(bias + 16 * ot + 4 * q);
         int base[NPT];      // tap (0,0) of this lane's pixel of tile i in plane q: one row up, one column left in the zero-bordered grid
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) { acc[i] = bv; base[i] = q * G16::NPIX + (tfirst + TSTEP * i) * G16::P + (lane & 15); }
+        for (int i = 0; i < NPT; ++i) { acc[i] = bv; base[i] = q * G16::NPIX + tile_of(wave, i) * G16::P + (lane & 15); }
+        if (skip || !active(wave)) return;
         // entry offset (compile-time part) of chunk c: its tap and its first channel quad
         auto off = [&](int c) {
             const int cc = c < NCH ? c : NCH - 1, tap = (4 * cc) / NQ, icq0 = 4 * cc - tap * NQ, dy = tap / 3, dx = tap - 3 * dy;
@@ -518,11 +534,20 @@ struct SeqConv1 {
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             f4 v = acc[i];
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            out_map[(4 * ot) * G16::NPIX + base[i] + G16::P + 1] = v;      // base carries q * NPIX
+            acc[i] = f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
         }
     }
+    // this lane's results of compute(): channels 4 (4 ot + q) .. + 3 of pixel (row tile_of(wave, i), column lane & 15)
+    __device__ static __forceinline__ int out_entry(int wave, int lane, int i) {       // entry inside ONE plane set: quad * NPIX + pixel
+        return (4 * ot_of(wave) + (lane >> 4)) * G16::NPIX + G16::interior(tile_of(wave, i), lane & 15);
+    }
 };
+// the k-th entry of a plane that is not an interior pixel: the border rows and columns of the (F + 2) x (F + 2) grid and the plane's tail
+constexpr int SEQ_HALO = G16::NPIX - 16 * 16;
+__device__ __forceinline__ int seq_halo_pix(int k) {
+    constexpr int P = G16::P;
+    return k < P ? k : (k < 2 * P ? (P - 1) * P + (k - P) : (k < 2 * P + 32 ? (1 + ((k - 2 * P) >> 1)) * P + ((k - 2 * P) & 1) * (P - 1) : P * P + (k - 2 * P - 32)));
+}
 
 // conv3 (16 -> 8) and conv4 (8 -> 4) of the sequential head on v_mfma_f32_4x4x1_16B_f32 (sixteen independent 4 x 4 blocks, K = 1):
 // on the 16 x 16 MFMA these layers fill 8 and 4 of the 16 output rows; here a block's rows are ONE group of four output channels
@@ -558,8 +583,8 @@ struct SeqConvQ {
 #pragma unroll
         for (int kg = 0; kg < NKR; ++kg) wr[kg] = wq[(size_t)(wave % NG) * KP * 4 + kg * 64 + lane];
     }
-    __device__ __forceinline__ void run(const f4* in_map, f4* out_map, const float* __restrict__ bias, int wave, int lane) {
-        if (wave >= JOBS) return;
+    // the ReLU'd output channels 4 g .. 4 g + 3 (g = wave % NG) of pixel 64 (wave / NG) + lane; waves >= JOBS have no job
+    __device__ __forceinline__ f4 compute(const f4* in_map, const float* __restrict__ bias, int wave, int lane) {
         const int g = wave % NG, pg = wave / NG;
         const int p = 64 * pg + lane, y = p >> 4, x = p & 15;
         const f4* in0 = in_map + y * G16::P + x;                                 // tap (0, 0) of this lane's pixel
@@ -585,7 +610,12 @@ struct SeqConvQ {
         }
         f4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        out_map[g * G16::NPIX + G16::interior(y, x)] = v;
+        return v;
+    }
+    __device__ __forceinline__ void run(const f4* in_map, f4* out_map, const float* __restrict__ bias, int wave, int lane) {
+        if (wave >= JOBS) return;
+        const int p = 64 * (wave / NG) + lane;
+        out_map[(wave % NG) * G16::NPIX + G16::interior(p >> 4, p & 15)] = compute(in_map, bias, wave, lane);
     }
 };
 
@@ -601,15 +631,20 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     constexpr int F = 16, n = F * F;
     static_assert(NW * 64 >= n, "one thread per pixel in the 1 x 1 stage");
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    f4* m1 = reinterpret_cast<f4*>(sm);                          // 8 quads (the fp32 maps first: their offsets fit the LDS
-    f4* m2 = m1 + (W1 / 4) * G16::NPIX;                          // 4 quads  instructions' 16-bit offset field)
-    float* sc = reinterpret_cast<float*>(m2 + 4 * G16::NPIX);    // the score plane, for the decode's argmax
+    // region R (the first 63 KiB; offsets inside the DS instructions' 16-bit field): conv1's output as PIECES, 3 x 8 quads of 8-byte
+    // entries -- and, once conv2 has read them, the fp32 maps of conv2 (4 quads) and conv3 (2) in the same bytes
+    u32x2* m1p = reinterpret_cast<u32x2*>(sm);
+    f4* m2 = reinterpret_cast<f4*>(sm);
+    f4* m3 = m2 + 4 * G16::NPIX;
+    constexpr int R_F4 = (W1 / 4 + 4) * G16::NPIX;
+    static_assert(R_F4 * 16 == 3 * (W1 / 4) * G16::NPIX * 8 && 6 * G16::NPIX <= R_F4, "conv1's pieces fill the region the fp32 maps shared");
+    float* sc = reinterpret_cast<float*>(m2 + R_F4);             // the score plane, for the decode's argmax
     u32x2* in_map = reinterpret_cast<u32x2*>(sc + 256);          // 3 pieces x 12 quads
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    SeqConv1<NW, MAXP> c1;
+    SeqConvB<C, W1, NW, MAXP> c1;
     int nstamp = 0;
     auto stamp = [&]() {
         if constexpr (DIAG) {
@@ -618,7 +653,7 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
         }
     };
     stamp();
-    vth::HeadConv<W1, 16, F, NW> c2;
+    SeqConvB<W1, 16, NW, VT_SEQ3_C2_MAXP, VT_SEQ3_C2_ACT> c2;
     SeqConvQ<16, 8, NW> c3;
     SeqConvQ<8, 4, NW> c4;
     c1.prefetch(hw3 + O3_W1, wave, lane);      // first weight pass flies during the map set-up
@@ -629,51 +664,95 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
     f4 tok[NST];
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
-        const int i = threadIdx.x + k * NW * 64, icq = i / n, pix = i % n;
+        // item i = ((pixel group pg, quad group r), lane = (c4, px)): pixel 16 pg + px, channel quad 4 r + c4.  A wave-load reads 16 rows x
+        // 64 B (four lanes per row), and a 16-lane pass of the LDS writes below is 16 consecutive entries of ONE plane: conflict-free.
+        // (Lanes along the pixels of one quad read 64 rows at a 192-byte stride; lanes along a row's quads write 12 planes, 6-way conflicts.)
+        const int i = threadIdx.x + k * NW * 64, g = i >> 6, pix = 16 * (g / 3) + (i & 15), icq = 4 * (g % 3) + ((i >> 4) & 3);
         tok[k] = ld4(feat + ((size_t)b * n + pix) * C + 4 * icq);
     }
-    for (int i = threadIdx.x; i < SEQ3_LDS_BYTES / 16; i += NW * 64) reinterpret_cast<u32x4*>(sm)[i] = u32x4{0, 0, 0, 0};
-    __syncthreads();
+#ifdef VT_SEQ3_START_STAMPS
     stamp();
+#endif
+    // zero borders: only what is READ without having been written -- the border entries of the input's 36 piece planes and of piece 2 of
+    // conv1's output (pieces 0 / 1 and the fp32 maps get theirs per tower, below).  Clearing all 160 KB cost 6.9 k cycles per frame.
+    constexpr int PS1_ = (W1 / 4) * G16::NPIX;
+    // thread -> (plane of the pass, border entry): HPP planes per pass; the entry's pixel is computed once per call, a pass costs an add
+    constexpr int HPP = NW * 64 / SEQ_HALO;
+    auto zero_borders = [&](auto* planes, int nplanes, auto zero) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int pl = tid / SEQ_HALO, hp = seq_halo_pix(tid - pl * SEQ_HALO);
+        if (pl < HPP)
+            for (int p0 = 0; p0 < nplanes; p0 += HPP)
+                if (p0 + pl < nplanes) planes[(p0 + pl) * G16::NPIX + hp] = zero;
+    };
+    zero_borders(in_map, 3 * (C / 4), u32x2{0u, 0u});
+    zero_borders(m1p + 2 * PS1_, W1 / 4, u32x2{0u, 0u});
+    stamp();
+#ifdef VT_SEQ3_START_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();
+#endif
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
-        const int i = threadIdx.x + k * NW * 64, icq = i / n, pix = i % n;
+        const int i = threadIdx.x + k * NW * 64, g = i >> 6, pix = 16 * (g / 3) + (i & 15), icq = 4 * (g % 3) + ((i >> 4) & 3);
         u32x2 h, m, l;
         split3(tok[k], h, m, l);
         const int e = icq * G16::NPIX + G16::interior(pix / F, pix % F);
         in_map[e] = h; in_map[(C / 4) * G16::NPIX + e] = m; in_map[2 * (C / 4) * G16::NPIX + e] = l;
     }
+#ifdef VT_SEQ3_START_STAMPS
+    stamp();
+#endif
     __syncthreads();
 #pragma unroll 1
     for (int t = 0; t < 3; ++t) {              // tower 0 = ctr, 1 = offset, 2 = size
         const float* __restrict__ tw = hw + (size_t)t * vth::TOWER_STRIDE;
         const u32x4* __restrict__ tw3 = hw3 + (size_t)t * TOWER3_STRIDE;
         stamp();
-        if (!(VT_H3_SKIP & 1)) c1.run(in_map, m1, tw3 + O3_W1, tw + vth::O_B1, wave, lane);
-        c2.prefetch(tw + vth::O_W2, wave, lane);    // (not before conv1: its working set is 200 registers)
-        c3.prefetch(tw + vth::O_W3Q, wave, lane);
+        constexpr int PS1 = (W1 / 4) * G16::NPIX;                 // entries per piece of conv1's output
+        {
+            f4 r1[decltype(c1)::NPT];
+            c1.compute(in_map, tw3 + O3_W1, tw + vth::O_B1, wave, lane, (VT_H3_SKIP & 1) != 0, r1);
+            c2.prefetch(tw3 + O3_W2, wave, lane);    // (not before conv1: its working set is 200 registers)
+            __syncthreads();                         // the previous tower's conv4 has read m3, which lies inside R
+#pragma unroll
+            for (int i = 0; i < decltype(c1)::NPT; ++i) {
+                u32x2 h, m, l;
+                split3(r1[i], h, m, l);
+                const int e = decltype(c1)::out_entry(wave, lane, i);
+                m1p[e] = h; m1p[PS1 + e] = m; m1p[2 * PS1 + e] = l;
+            }
+            // the borders of pieces 0 and 1 held interior values of the previous tower's fp32 maps (piece 2's bytes are never reused)
+            zero_borders(m1p, 2 * (W1 / 4), u32x2{0u, 0u});
+        }
         stamp();
         __syncthreads();
         stamp();
-        if (!(VT_H3_SKIP & 2)) c2.run(m1, m2, tw + vth::O_W2, tw + vth::O_B2, wave, lane);
+        {
+            f4 r2[decltype(c2)::NPT];
+            c2.compute(m1p, tw3 + O3_W2, tw + vth::O_B2, wave, lane, (VT_H3_SKIP & 2) != 0, r2);
+            c3.prefetch(tw + vth::O_W3Q, wave, lane);
+            __syncthreads();                         // every wave has read conv1's pieces: conv2's fp32 map may overwrite them
+#pragma unroll
+            for (int i = 0; i < decltype(c2)::NPT; ++i)
+                if (decltype(c2)::active(wave)) m2[decltype(c2)::out_entry(wave, lane, i)] = r2[i];
+            zero_borders(m2, 6, splat4(0.f));        // borders of m2 (4 planes) and of m3 (2 planes, contiguous with them)
+        }
         c4.prefetch(tw + vth::O_W4Q, wave, lane);
         stamp();
         __syncthreads();
         stamp();
-        if (!(VT_H3_SKIP & 8)) c3.run(m2, m1, tw + vth::O_B3, wave, lane);
+        if (!(VT_H3_SKIP & 8)) c3.run(m2, m3, tw + vth::O_B3, wave, lane);
         stamp();
         __syncthreads();
         stamp();
-        if (!(VT_H3_SKIP & 8)) c4.run(m1, m2, tw + vth::O_B4, wave, lane);
-        if (t < 2) c1.prefetch(tw3 + TOWER3_STRIDE + O3_W1, wave, lane);   // the next tower's first pass
-        stamp();
-        __syncthreads();
-        stamp();
-        // 1x1 conv + activation (head.py:187,194,200-201) -> global maps (+ the score plane in LDS)
-        if (threadIdx.x < n) {
-            int pix = threadIdx.x;
+        // conv4 and the 1 x 1 conv + activation (head.py:187,194,200-201) in one go: a lane of waves 0-3 ends conv4 with its pixel's four
+        // channels in registers, which is all the 1 x 1 stage reads -> global maps (+ the score plane in LDS); no map, no barrier
+        if (wave < decltype(c4)::JOBS) {
+            const f4 v = (VT_H3_SKIP & 8) ? splat4(0.f) : c4.compute(m3, tw + vth::O_B4, wave, lane);
+            int pix = 64 * wave + lane;
             asm volatile("" : "+v"(pix));      // addresses are rebuilt here per tower: hoisted out of the tower loop they were spilled
-            const f4 v = m2[G16::interior(pix / F, pix % F)];
             const int nout = (t == 0) ? 1 : 2;
             for (int o = 0; o < nout; ++o) {
                 const f4 w5 = ld4(tw + vth::O_W5 + 4 * o);
@@ -684,8 +763,10 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
                 else offset[((size_t)b * 2 + o) * n + pix] = y;
             }
         }
-        // the next tower's conv1 writes m1 (last read by c4, before the barrier above) and its conv2 writes m2 only after
-        // the barrier that follows conv1: the 1x1 reads of m2 above need no barrier of their own
+        if (t < 2) c1.prefetch(tw3 + TOWER3_STRIDE + O3_W1, wave, lane);   // the next tower's first pass
+        stamp();
+        stamp();
+        // the next tower's conv1 writes R only behind the barrier in front of its epilogue: conv4's reads of m3 need none of their own
     }
     // size / offset of this frame were written by this workgroup's own threads: the barrier (workgroup-scope release / acquire)
     // makes them visible to the decoding wave
