@@ -359,8 +359,17 @@ __global__ __launch_bounds__(768) void head_fused3_kernel(const float* __restric
     const f4 fv = ld4(feat + ((size_t)b * 64 + (threadIdx.x & 63)) * C + 4 * (threadIdx.x >> 6));     // requested before the LDS is cleared
     float win = 0.f;
     if (wave == 0 && window != nullptr) win = window[lane];
-    for (int i = threadIdx.x; i < (IN_E + 3 * (M1_E + M2_E)) / 2; i += 768) reinterpret_cast<u32x4*>(in_map)[i] = u32x4{0, 0, 0, 0};
-    __syncthreads();
+    // zero what is read without ever being written: per plane the border rows (entries [0, P) and [(F + 1) P, (F + 2) P)) and the zero tail
+    // behind them -- 48 of a plane's 112 entries; the interiors are written (staging, layer epilogues) before they are read.  No barrier
+    // between this and the staging: they touch different entries.
+    {
+        constexpr int NPL = (IN_E + 3 * (M1_E + M2_E)) / G::NPIX, ZU = (G::NPIX - F * G::P) / 2, TOPU = G::P / 2;     // planes; 16-byte units to zero per plane; of them the top row
+        static_assert(G::P % 2 == 0 && G::NPIX % 2 == 0 && ((F + 1) * G::P) % 2 == 0, "16-byte units");
+        for (int j = threadIdx.x; j < NPL * ZU; j += 768) {
+            const int pl = j / ZU, u = j - pl * ZU;
+            reinterpret_cast<u32x4*>(in_map + pl * G::NPIX)[u < TOPU ? u : (F + 1) * G::P / 2 + (u - TOPU)] = u32x4{0, 0, 0, 0};
+        }
+    }
     {
         const int icq = threadIdx.x >> 6, pix = threadIdx.x & 63;
         u32x2 h, m, l;
