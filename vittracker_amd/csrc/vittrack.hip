@@ -101,6 +101,7 @@ struct vt_model {
     int tile_frames = 0;             // frames those workspaces are sized for
     int blocks_tile = -1;            // 1 / 0 force the tile-parallel form of the blocks / forbid it, -1 (default): by batch size
     DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
+    DevBuf vlscr;                    // G256 frame-form block kernel (A3): the low pieces of V^T, [B][depth][3][L / 32][64] x 16 B (vt_blocks.h VP2L)
     int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
     int tmpl_form_batch = 0;         // the form batch vt_set_template ran under (the cache holds THAT form's operands)
     int graphs_captured = 0;         // vt_graph_capture[_steps] calls that succeeded: their graphs hold the forms of their capture
@@ -575,13 +576,17 @@ size_t blocks_lds_bytes(int NT, bool WLDS, bool BAL, int depth, bool BF3 = false
 }
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
+// floats of V^T low-piece scratch per frame (vt_blocks.h VP2L): depth x NC feature tiles x L / 32 chunk pairs x 64 lanes x 16 B
+size_t vlscr_floats_per_frame(const vt_model* m) { return (size_t)m->cfg.depth * vtb::NC * (m->L / 32) * 64 * 4; }
+
 template <int NT, int NW, int TPW, bool WLDS, bool BAL = false, bool ZC = false, bool BF3 = false, bool A3 = false>
-int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode) {
+int launch_blocks(vt_model* m, hipStream_t st, const float* tokens, int B, int nblocks, float* feat, float* resid, int zcache_mode, size_t f0 = 0) {
     if (zcache_mode != 0 && !ZC)
         return fail(VT_ERR_STATE, "the template cache needs the default block kernel (VT_BLOCKS_BAL = 1)");
     const size_t lds = blocks_lds_bytes(NT, WLDS, BAL, m->cfg.depth, BF3, A3);
     hipLaunchKernelGGL((vtb::blocks_kernel<NT, NW, TPW, WLDS, BAL, ZC, BF3, A3>), dim3(B), dim3(NW * 64), lds, st, tokens, m->blocks.p, feat,
-                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode, m->blocks3.p);
+                       resid, m->len_z, m->cfg.depth, nblocks, m->dbg_skip_tile, m->dbg_stamps, m->zcache.p, zcache_mode, m->blocks3.p,
+                       m->vlscr.p ? reinterpret_cast<unsigned*>(m->vlscr.p) + f0 * vlscr_floats_per_frame(m) : nullptr);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -648,8 +653,8 @@ int run_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
         case 20:   // 8 waves: waves s and s+4 share SIMD s with 3 + 2 tiles, so each SIMD has two instruction streams
 #ifndef VT_F16
             if (m->blocks_bal && m->blocks_bf3_g256 >= 2)
-                return zc ? launch_blocks<20, 8, 3, false, false, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
-                          : launch_blocks<20, 8, 3, false, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc);
+                return zc ? launch_blocks<20, 8, 3, false, false, true, true, true>(m, st, tokens, B, nblocks, feat, resid, zc, f0)
+                          : launch_blocks<20, 8, 3, false, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc, f0);
             if (m->blocks_bal && m->blocks_bf3_g256)
                 return zc ? launch_blocks<20, 8, 3, false, false, true, true>(m, st, tokens, B, nblocks, feat, resid, zc)
                           : launch_blocks<20, 8, 3, false, false, false, true>(m, st, tokens, B, nblocks, feat, resid, zc);
@@ -1052,6 +1057,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
     A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
     A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
+    if (m->L / 16 == 20) A(m->vlscr, B * vlscr_floats_per_frame(m));
     m->tile_frames = (int)std::min<size_t>(B, 128);
     A(m->tile_q, 2 * (size_t)m->tile_frames * m->L * 48);      // two sets each (launch_blocks_tile)
     A(m->tile_k, 2 * (size_t)m->tile_frames * m->L * 48);
@@ -1218,7 +1224,7 @@ void vt_destroy(vt_model* m) {
     m->stem_w3b.release();
     m->stem_w4b.release();
     m->act_x.release(); m->act_z.release();
-    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->blocks3, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->tokens_c,
+    DevBuf* all[] = {&m->pos_z, &m->pos_x, &m->blocks, &m->blocks3, &m->head, &m->head3, &m->window, &m->tokens, &m->feat, &m->zcache, &m->vlscr, &m->tokens_c,
                      &m->tile_q, &m->tile_k, &m->tile_v, &m->tile_x, &m->head_m1,
                      &m->score, &m->size, &m->offset, &m->pred, &m->hann, &m->conf};
     for (DevBuf* d : all) d->release();

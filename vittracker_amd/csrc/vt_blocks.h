@@ -253,7 +253,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                                                          // [B][len_z/16][9][64] f4: q, k, v^T images of each template tile.
                                                          float* __restrict__ zcache,
                                                          int zcache_mode,     // 0: off, 1: compute and store, 2: load instead of computing
-                                                         const float* __restrict__ params3) {   // BF3: the MLP's three-piece images, BLOCK3_STRIDE per block
+                                                         const float* __restrict__ params3,   // BF3: the MLP's three-piece images, BLOCK3_STRIDE per block
+                                                         unsigned* __restrict__ vlscr) {      // VP2L (the G256 A3 form): the low pieces of V^T, [B][depth][NC][NT / 2][64] x 16 B
     static_assert(NW * TPW >= NT, "tiles must be covered");
     // BF3L: the LDS-staged form (G128 balanced frame form: qkv + MLP); BF3G: weights from L2 as in every !WLDS form (G256: MLP only)
     constexpr bool BF3L = BF3 && WLDS, BF3G = BF3 && !WLDS;
@@ -264,6 +265,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     // the G256 form (BF3G) has LDS for the K pieces only (90 KiB) beside the fp32 V^T image (60 KiB): q k^T and proj run on the bf16 pipe,
     // P.V stays on fp32 MFMAs
     constexpr bool VP3 = A3 && BF3L;
+    // VP2L (round 5): the G256 form's V^T as pieces after all -- the high and middle pieces take exactly the fp32 image's 60 KiB of LDS, the
+    // LOW pieces (used by one of a product's six terms) go through a per-frame, per-block scratch in global memory: written by the wave
+    // that computes them, read back (L2) as that term's A operand.  P.V then runs on the bf16 pipe: 180 instead of 240 matrix instructions
+    // per query tile, each half as long.
+    constexpr bool VP2L = A3 && BF3G;
     constexpr int KP_T16 = W3_FC1_OT16, VP_PAIRS = NT / 2, VP_T16 = VP_PAIRS * 3 * 64 + (NT & 1) * 3 * 32;
     constexpr int KV_UNITS = A3 ? NT * KP_T16 + (VP3 ? NC * VP_T16 : NC * NT * 64) : 2 * NT * NC * 64;
     constexpr int L = NT * 16;
@@ -482,6 +488,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 for (int pc = 0; pc < 3; ++pc) base[(((T >> 1) * 3 + pc) * 64 + lane3) * 2 + (T & 1)] = pv[pc];
             }
         };
+        // VP2L: V^T chunk T of feature tile ot -- h and m to LDS as [feature tile][chunk pair][piece 2][64 lanes] x 16 B (a pair's two chunks are
+        // the two halves of a lane's 16 bytes), l to this block's scratch plane [feature tile][chunk pair][64 lanes] x 16 B
+        constexpr int VL_BLK_U4 = NC * VP_PAIRS * 64;
+        u32x4* const vl_blk = VP2L ? reinterpret_cast<u32x4*>(vlscr) + ((size_t)b * depth_total + blk) * VL_BLK_U4 : nullptr;
+        auto store_v2l = [&](int T, int ot, f4 r) {
+            u32x2 pv[3];
+            vt3::split3(r, pv[0], pv[1], pv[2]);
+            const int pp = T >> 1, hf = T & 1;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) reinterpret_cast<u32x2*>(Vimg)[((((ot * VP_PAIRS + pp) * 2 + pc) * 64) + lane3) * 2 + hf] = pv[pc];
+            reinterpret_cast<u32x2*>(vl_blk)[(((ot * VP_PAIRS + pp) * 64) + lane3) * 2 + hf] = pv[2];
+        };
         if constexpr (A3 && BF3L) {
             stage_tiles(Wb, P3 + (W3_FC1_TILES + W3_FC2_TILES + W3_QKV_TILES) * 256, W3_PROJ_TILES, w, NW, lane, blk == 0);
         } else if constexpr (BF3L) {
@@ -504,6 +522,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 for (int ot = 0; ot < NC; ++ot) {
                     qr[i][ot] = zc[ot * 64];
                     if constexpr (VP3) store_v3(T, ot, zc[(2 * NC + ot) * 64]);
+                    else if constexpr (VP2L) store_v2l(T, ot, zc[(2 * NC + ot) * 64]);
                     else Vo[(ot * NT + T) * 64 + lane] = to_opnd(zc[(2 * NC + ot) * 64]);
                     if constexpr (!A3) Ko[(T * NC + ot) * 64 + lane] = to_opnd(zc[(NC + ot) * 64]);
                 }
@@ -563,6 +582,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                                     if (ot == NC - 1) store_k3(Kimg + T * KP_T16, kr);
                                 } else store_k3c(Kimg + T * KP_T16, ot, r);      // the 20-tile form has no registers for kr
                             } else if constexpr (VP3) store_v3(T, ot, r);
+                            else if constexpr (VP2L) store_v2l(T, ot, r);
                             else Vo[(ot * NT + T) * 64 + lane] = to_opnd(r);
                         }
                         else if (t < 2 * NC) Ko[(T * NC + ot) * 64 + lane] = to_opnd(r);
@@ -682,6 +702,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             }
         }
         stamp();            // QKV done
+        if constexpr (VP2L) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the low V^T pieces have reached L2 (measured: free -- the phase's stamps do not move)
         barrier_publish<WLDS>();    // K/V published; proj weights landed; buffer A free
         stamp();
         if constexpr (BF3L) {
@@ -794,8 +815,58 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                     }
 #pragma unroll
                     for (int t = 0; t < NC; ++t) o[t] = (oA[t] + oB[t]) * splat4(rden);
+                } else if constexpr (VP2L) {
+                    // O^T = V^T P^T pair by pair: a key-chunk pair's exponentials are split where they are produced (12 registers of pieces
+                    // alive at a time, not the 120 of all ten pairs) and go straight into the pair's 18 MFMAs; V^T's h / m pieces from LDS, its l
+                    // pieces from the block's scratch plane, requested a pair ahead
+                    const auto Vp2 = lds_lane_base<u32x4>(Vimg, 16u * lane3);      // [((t * VP_PAIRS + pp) * 2 + pc) * 64]
+                    const u32x4* const vlg = vl_blk + lane3;
+                    u32x4 vl[2][NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) vl[0][t] = vlg[(t * VP_PAIRS) * 64];
+                    f4 oA[NC];
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) oA[t] = splat4(0.f);
+#pragma unroll
+                    for (int pp = 0; pp < VP_PAIRS; ++pp) {
+                        if (pp + 1 < VP_PAIRS) {
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) vl[(pp + 1) & 1][t] = vlg[(t * VP_PAIRS + pp + 1) * 64];
+                        }
+                        u32x4 v[NC][2];
+#pragma unroll
+                        for (int t = 0; t < NC; ++t)
+#pragma unroll
+                            for (int pc = 0; pc < 2; ++pc) v[t][pc] = Vp2[((t * VP_PAIRS + pp) * 2 + pc) * 64];
+                        u32x2 pj[2][3];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int J = 2 * pp + jj;
+                            const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
+                            const f2 c = __builtin_elementwise_fma(f2{s[J].z, s[J].w}, k2, nm2);
+                            const f2 ea = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                            const f2 ec = {__builtin_amdgcn_exp2f(c.x), __builtin_amdgcn_exp2f(c.y)};
+                            d0 += ea;
+                            d1 += ec;
+                            vt3::split3(f4{ea.x, ea.y, ec.x, ec.y}, pj[jj][0], pj[jj][1], pj[jj][2]);
+                        }
+                        u32x4 pb[3];
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) pb[pc] = u32x4{pj[0][pc].x, pj[0][pc].y, pj[1][pc].x, pj[1][pc].y};
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e)
+#pragma unroll
+                            for (int t = 0; t < NC; ++t) oA[t] = vt3::mma(TW[e] == 2 ? vl[pp & 1][t] : v[t][TW[e] & 1], pb[TX[e]], oA[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const f2 dd = d0 + d1;
+                    const float rden = __builtin_amdgcn_rcpf(quad_sum(dd.x + dd.y));
+                    fstamp();
+#pragma unroll
+                    for (int t = 0; t < NC; ++t) o[t] = oA[t] * splat4(rden);
                 } else {
-                    // V^T stays an fp32 image (G256: no LDS for its pieces): exponentials in place, O^T = V^T P^T on fp32 MFMAs
+                    // V^T stays an fp32 image: exponentials in place, O^T = V^T P^T on fp32 MFMAs
 #pragma unroll
                     for (int J = 0; J < NT; ++J) {
                         const f2 a = __builtin_elementwise_fma(f2{s[J].x, s[J].y}, k2, nm2);
