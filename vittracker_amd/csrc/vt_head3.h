@@ -592,10 +592,16 @@ struct SeqConvQ {
 #pragma unroll
         for (int kg = 0; kg < NKR; ++kg) wr[kg] = wq[(size_t)(wave % NG) * KP * 4 + kg * 64 + lane];
     }
-    // the ReLU'd output channels 4 g .. 4 g + 3 (g = wave % NG) of pixel 64 (wave / NG) + lane; waves >= JOBS have no job
+    // Pixel of (pixel group pg, lane): column lane & 15 of row 2 pg + (lane >> 5) + 8 ((lane >> 4) & 1) -- the four 16-lane rows of a wave are
+    // map rows r, r + 8, r + 1, r + 9.  A ds_read_b128 is served in groups that mix lanes 0-3 / 12-15 with lanes 20-27 (and 32-35 / 44-47 with
+    // 52-59): with those on ADJACENT rows (row pitch 18 x 16 B = 72 dwords: bank offset 8) columns 12-13 of one row and 10-11 of the next
+    // share banks and every read and write of the fp32 maps took 8 LDS cycles instead of 4 (1.16 M conflict cycles per launch, all of the
+    // kernel's); eight rows apart the offset is 576 dwords = 0 mod 64 (tools/lds_conflicts.py).
+    __device__ static __forceinline__ int pixel_of(int pg, int lane) { return 16 * (2 * pg + (lane >> 5) + 8 * ((lane >> 4) & 1)) + (lane & 15); }
+    // the ReLU'd output channels 4 g .. 4 g + 3 (g = wave % NG) of pixel pixel_of(wave / NG, lane); waves >= JOBS have no job
     __device__ __forceinline__ f4 compute(const f4* in_map, const float* __restrict__ bias, int wave, int lane) {
         const int g = wave % NG, pg = wave / NG;
-        const int p = 64 * pg + lane, y = p >> 4, x = p & 15;
+        const int p = pixel_of(pg, lane), y = p >> 4, x = p & 15;
         const f4* in0 = in_map + y * G16::P + x;                                 // tap (0, 0) of this lane's pixel
         f4 acc[4] = {ld4(bias + 4 * g), splat4(0.f), splat4(0.f), splat4(0.f)};
         f4 bv[2][NQ];
@@ -623,7 +629,7 @@ struct SeqConvQ {
     }
     __device__ __forceinline__ void run(const f4* in_map, f4* out_map, const float* __restrict__ bias, int wave, int lane) {
         if (wave >= JOBS) return;
-        const int p = 64 * (wave / NG) + lane;
+        const int p = pixel_of(wave / NG, lane);
         out_map[(wave % NG) * G16::NPIX + G16::interior(p >> 4, p & 15)] = compute(in_map, bias, wave, lane);
     }
 };
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(NW * 64) void head_seq3_kernel(const float* __restr
         // channels in registers, which is all the 1 x 1 stage reads -> global maps (+ the score plane in LDS); no map, no barrier
         if (wave < decltype(c4)::JOBS) {
             const f4 v = (VT_H3_SKIP & 8) ? splat4(0.f) : c4.compute(m3, tw + vth::O_B4, wave, lane);
-            int pix = 64 * wave + lane;
+            int pix = decltype(c4)::pixel_of(wave, lane);
             asm volatile("" : "+v"(pix));      // addresses are rebuilt here per tower: hoisted out of the tower loop they were spilled
             const int nout = (t == 0) ? 1 : 2;
             for (int o = 0; o < nout; ++o) {
