@@ -29,7 +29,7 @@ DEFAULT_VIT48 = [
     (r"vts::stem_a_kernel", 256), (r"vts::stem_b_kernel<false>", 256),
     (r"vtb::tile_qkv_kernel<(5|20)>", 512), (r"vtb::tile_attn_mlp_kernel<(5|20)>", 256),
     (r"vth3::head_towers3_kernel", 256), (r"vth::head_towers_kernel<16, 8, false, (false|true)>", 256), (r"vth::head_conv1_kernel<16>", 256),
-    (r"vth::decode_kernel", 512), (r"vtt::crop_kernel<(false|true)>", 256), (r"vtt::update_state_kernel", 512),
+    (r"vth::decode_kernel", 512), (r"vtt::crop_kernel<(false|true)>", 256), (r"vtt::crop_fast_kernel<[124]>", 256), (r"vtt::update_state_kernel", 512),
     # fp32-MFMA forms selected by VT_*_BF3=0 (bench.py's all-fp32 comparison)
     (r"vts::stem_fused_kernel<[012], false, false>", 128), (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), false, false>", 256),
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), false, false>", 256), (r"vth::head_fused_kernel<8, false>", 168),

@@ -846,6 +846,19 @@ std::mutex g_crop_mutex;
 
 void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const double* states, double factor, int T, const float* mean3,
                  const float* std3, int B, hipStream_t st, float* crops, double* rf) {
+    static const int fast = [] { const char* v = std::getenv("VT_CROP_FAST"); return v && *v ? std::atoi(v) : 1; }();     // groups per workgroup (1, 2, 4); 0: crop_kernel
+    if (!bytes && fast > 0 && (T & 3) == 0 && T <= vtt::CROP_FAST_MAX_T) {
+        const int ngroups = (T * (T / 4) + 255) / 256;
+        auto go = [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL(vtt::crop_fast_kernel<G>, dim3((ngroups + G - 1) / G, B), dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0],
+                               mean3[1], mean3[2], std3[0], std3[1], std3[2], crops, rf);
+        };
+        if (fast >= 4 && ngroups >= 4) go(std::integral_constant<int, 4>{});
+        else if (fast >= 2 && ngroups >= 2) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 1>{});
+        return;
+    }
     dim3 grid((T * ((T + 3) / 4) + 255) / 256, B);
     if (bytes)
         hipLaunchKernelGGL(vtt::crop_kernel<true>, grid, dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0], mean3[1], mean3[2],

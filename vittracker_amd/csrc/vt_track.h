@@ -169,6 +169,163 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     }
 }
 
+// The crop as the tracker's step runs it (T a multiple of 4, T <= CROP_FAST_MAX_T): same arithmetic, same results bit for bit as
+// crop_kernel (which stays: any T, the byte-load form, the reference of the device self test).  What differs:
+//   - a workgroup computes the T column entries of its frame ONCE into LDS (byte offset of the 8-byte window, the two 11-bit weights
+//     packed for v_dot2, the right column's bit offset) and walks G groups of 256 items (an item = four consecutive pixels of a row):
+//     the column table, the normalisation table and the fp64 box geometry are paid once per G x 12 output values of a thread
+//   - the walk is software-pipelined (group g + 1's eight window loads are issued before group g's arithmetic).  MEASURED (256 sequences,
+//     rocprofv3 of tracking/track_batch_demo.py, us per launch at G128 / G256; crop_kernel: 25.1 / 111.3): G = 1: 22.3 / 106.3,
+//     G = 2: 22.6 / 129.0, G = 4: 26.1 / 126.5 -- one item per thread stays the best shape, so G = 1 is what launch_crop uses;
+//     windows fetched as three ALIGNED dwords + funnel shift (half the address-path cycles by tools/src/probe_gather.hip): 26.2 / 111.5
+//     at G = 1, i.e. slower, and removed again.  The kernel is bound by neither its instruction count (a third of crop_kernel's in
+//     the arithmetic) nor the gather's address path alone; NOTES R5-8.
+//   - zero padding lives in the WEIGHTS: a column / row of the padded crop outside the frame gets weight 0, so the arithmetic carries
+//     no validity masks
+//   - the horizontal pass of a (row, channel) is v_perm_b32 (the channel's byte of the left and the right pixel into the two halves
+//     of a dword) + v_dot2_u32_u16 with the packed weights; the vertical pass's (b (r >> 4)) >> 16 is one v_mul_hi_u32_u24
+//   - a load that could cross the end of the buffer (the last rows of the last frame) shifts its window as crop_kernel does, on a
+//     slow path a whole wave takes or skips
+constexpr int CROP_FAST_MAX_T = 512;
+__device__ __forceinline__ unsigned mulhi24(unsigned a, unsigned b) {      // (a b) >> 32 for a, b < 2^24
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int G>
+__global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __restrict__ frames, int H, int W,
+                                                        const double* __restrict__ states, double factor, int T,
+                                                        float m0, float m1, float m2, float s0, float s1, float s2,
+                                                        float* __restrict__ out, double* __restrict__ resize_factor) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float norm_lut[3 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned xtab[CROP_FAST_MAX_T * 4];      // per output column: window byte offset, weights, right column's shift, -
+    {
+        const float meanv[3] = {m0, m1, m2}, stdq[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {       // Preprocessor.process on the 256 possible values: see crop_kernel
+            float scaled = (float)tid * (1.0f / 255.0f);
+            asm volatile("" : "+v"(scaled));
+            float centred = scaled - meanv[c];
+            asm volatile("" : "+v"(centred));
+            norm_lut[c * 256 + tid] = centred / stdq[c];
+        }
+    }
+    const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
+    const int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
+    const int T4 = T >> 2, nitems = T * T4;
+    const int item0 = blockIdx.x * G * 256;
+    if (!(crop_sz >= 1)) {                  // 'Too small bounding box.': NaN poison, as crop_kernel
+        if (blockIdx.x == 0 && tid == 0) resize_factor[b] = __builtin_nan("");
+        for (int g = 0; g < G; ++g) {
+            const int idx = item0 + g * 256 + tid;
+            if (idx < nitems) {
+                const int oy = idx / T4, ox0 = (idx - oy * T4) * 4;
+                for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + ox0, splat4(__builtin_nanf("")));
+            }
+        }
+        return;
+    }
+    const int x1 = (int)rint(bx + 0.5 * bw - crop_sz * 0.5);
+    const int y1 = (int)rint(by + 0.5 * bh - crop_sz * 0.5);
+    const int x2 = x1 + crop_sz, y2 = y1 + crop_sz;
+    const int vx0 = x1 < 0 ? 0 : x1, vx1 = x2 - (x2 - W + 1 > 0 ? x2 - W + 1 : 0);
+    const int vy0 = y1 < 0 ? 0 : y1, vy1 = y2 - (y2 - H + 1 > 0 ? y2 - H + 1 : 0);
+    if (blockIdx.x == 0 && tid == 0) resize_factor[b] = (double)T / (double)crop_sz;
+    const double scale = (double)crop_sz / (double)T;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    for (int ox = tid; ox < T; ox += 256) {
+        int sx0, sx1, ax0, ax1;
+        lin_coeff(ox, crop_sz, scale, sx0, sx1, ax0, ax1);
+        const int xx0 = x1 + sx0, xx1 = x1 + sx1;
+        const bool vc0 = xx0 >= vx0 && xx0 < vx1, vc1 = xx1 >= vx0 && xx1 < vx1;
+        const int xb = vc0 ? xx0 : (vc1 ? xx1 : 0);         // base pixel of the window: the left column when it is inside the frame
+        *reinterpret_cast<u4v*>(xtab + 4 * ox) = u4v{3u * (unsigned)xb, (unsigned)(vc0 ? ax0 : 0) | ((unsigned)(vc1 ? ax1 : 0) << 16),
+                                                      (unsigned)(vc1 ? 24 * (xx1 - xb) : 0), 0u};
+    }
+    __syncthreads();
+    const size_t frame_bytes = (size_t)H * W * 3, rest = (size_t)(gridDim.y - b) * frame_bytes;
+    const unsigned nrec = rest > 0xfffffff0ull ? 0xfffffff0u : (unsigned)rest;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames + (size_t)b * frame_bytes), 0, (int)nrec, 0x00020000);
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    struct Item {
+        unsigned long long q0[4], q1[4];
+        unsigned wp[4], sh[4], byw0, byw1;
+        int oy, ox0;
+        bool live;
+    };
+    auto fetch = [&](int g, Item& it) {
+        const int idx = item0 + g * 256 + tid;
+        it.live = idx < nitems;
+        const int idc = it.live ? idx : nitems - 1;
+        it.oy = idc / T4;
+        it.ox0 = (idc - it.oy * T4) * 4;
+        int sy0, sy1, by0, by1;
+        lin_coeff(it.oy, crop_sz, scale, sy0, sy1, by0, by1);
+        const int yy0 = y1 + sy0, yy1 = y1 + sy1;
+        const bool vr0 = yy0 >= vy0 && yy0 < vy1, vr1 = yy1 >= vy0 && yy1 < vy1;
+        const unsigned rowo0 = (unsigned)(vr0 ? yy0 : 0) * (unsigned)(W * 3), rowo1 = (unsigned)(vr1 ? yy1 : 0) * (unsigned)(W * 3);
+        it.byw0 = vr0 ? (unsigned)by0 << 12 : 0u;      // a padded row weighs nothing
+        it.byw1 = vr1 ? (unsigned)by1 << 12 : 0u;
+        // can a window of this item cross the end of the buffer?  (3 (W - 1) is the largest column offset)
+        const unsigned far = (rowo0 > rowo1 ? rowo0 : rowo1) + 3u * (unsigned)(W - 1) + 8u;
+        const bool slow = __builtin_amdgcn_ballot_w64(far > nrec) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u4v e = *reinterpret_cast<const u4v*>(xtab + 4 * (it.ox0 + k));
+            it.wp[k] = e.y; it.sh[k] = e.z;
+            const unsigned o0 = rowo0 + e.x, o1 = rowo1 + e.x;
+            if (slow) {
+                const unsigned ov0 = o0 + 8u > nrec ? o0 + 8u - nrec : 0u, ov1 = o1 + 8u > nrec ? o1 + 8u - nrec : 0u;
+                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o0 - ov0), 0, 0);
+                const u2v c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o1 - ov1), 0, 0);
+                it.q0[k] = (((unsigned long long)a.y << 32) | a.x) >> (8u * ov0);
+                it.q1[k] = (((unsigned long long)c.y << 32) | c.x) >> (8u * ov1);
+            } else {
+                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o0, 0, 0);
+                const u2v c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o1, 0, 0);
+                it.q0[k] = ((unsigned long long)a.y << 32) | a.x;
+                it.q1[k] = ((unsigned long long)c.y << 32) | c.x;
+            }
+        }
+    };
+    auto finish = [&](const Item& it) {
+        float res[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned l0 = (unsigned)it.q0[k], l1 = (unsigned)it.q1[k];
+            const unsigned r0w = __builtin_amdgcn_alignbit((unsigned)(it.q0[k] >> 32), l0, it.sh[k]);       // the window >> 0 or 24 bits
+            const unsigned r1w = __builtin_amdgcn_alignbit((unsigned)(it.q1[k] >> 32), l1, it.sh[k]);
+            const us2 wv = __builtin_bit_cast(us2, it.wp[k]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // bytes of the result: [left pixel's channel c, 0, right pixel's channel c, 0]
+                const unsigned sel = 0x0c040c00u + 0x00010001u * (unsigned)c;
+                const unsigned r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r0w, l0, sel)), wv, 0u, false);
+                const unsigned r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r1w, l1, sel)), wv, 0u, false);
+                // (b (r >> 4)) >> 16 = ((b << 12) (r with its low 4 bits cleared)) >> 32: one 24-bit high multiply (both factors < 2^24)
+                const unsigned t0 = mulhi24(it.byw0, r0 & ~15u), t1 = mulhi24(it.byw1, r1 & ~15u);
+                // v = (t0 + t1 + 2) >> 2, clamped at 255; its table entry is at byte 4 v
+                unsigned v4 = (t0 + t1 + 2u) & ~3u;
+                v4 = v4 > 1020u ? 1020u : v4;
+                res[c][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(norm_lut) + c * 1024 + v4);
+            }
+        }
+        if (it.live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + it.oy) * T + it.ox0, f4{res[c][0], res[c][1], res[c][2], res[c][3]});
+        }
+    };
+    Item buf[2];
+    fetch(0, buf[0]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) fetch(g + 1, buf[(g + 1) & 1]);
+        finish(buf[g & 1]);
+    }
+}
+
 // One thread per sequence.  hann_boxes (B,4) float [cx,cy,w,h] in [0,1]; states (B,4) double in/out.
 // `record` (optional, (B,5) double, device memory or device-mapped pinned host memory): [x, y, w, h, confidence] of the new state --
 // what track() returns; written here, the step needs no copy kernel and no device -> host copy after it.
