@@ -1070,7 +1070,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
     A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
     A(m->zcache, B * (size_t)(m->len_z / 16) * 9 * 256);
-    if (m->L / 16 == 20) A(m->vlscr, B * vlscr_floats_per_frame(m));
+    if (m->L / 16 == 20 && !VT_IS_F16) A(m->vlscr, B * vlscr_floats_per_frame(m));      // (the f16 build's block kernels keep V^T as one f16 image)
     m->tile_frames = (int)std::min<size_t>(B, 128);
     A(m->tile_q, 2 * (size_t)m->tile_frames * m->L * 48);      // two sets each (launch_blocks_tile)
     A(m->tile_k, 2 * (size_t)m->tile_frames * m->L * 48);

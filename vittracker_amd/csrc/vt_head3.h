@@ -24,10 +24,10 @@
 
 #ifndef VT_F16
 #ifndef VT_SEQ3_C2_MAXP
-#define VT_SEQ3_C2_MAXP 5     // head_seq3's conv2: chunk pairs (= taps) per weight pass and waves that work on it (SeqConvB)
+#define VT_SEQ3_C2_MAXP 5     // head_seq3's conv2: chunk pairs (= taps) per weight pass -- 5 + 4: 0 B of scratch; all 9 resident: 44 B (NOTES R5-9)
 #endif
 #ifndef VT_SEQ3_C2_ACT
-#define VT_SEQ3_C2_ACT 8
+#define VT_SEQ3_C2_ACT 8      // waves that work on it; 4 (half the weight stream, four tiles per wave) compiles to 40-136 B of scratch: not used
 #endif
 #ifndef VT_H3_SKIP
 #define VT_H3_SKIP 0       // timing experiments only (wrong results): 1 = no conv1, 2 = no conv2-4 MFMAs (head_seq3: no conv2), 4 = no weight loads in conv1's steady state,
