@@ -99,6 +99,36 @@ print("BYTES-OK")
     assert p.returncode == 0 and "BYTES-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
+@pytest.mark.parametrize("form", ["0", "2", "4"])
+def test_every_crop_kernel_form_equals_the_host_crop(form):
+    """VT_CROP_FAST selects the tracker step's crop kernel: 1 (default; the tests above) = crop_fast_kernel with one group of 256 items per
+    workgroup, 2 / 4 = its software-pipelined multi-group walks, 0 = crop_kernel (which also serves every size that is not a multiple
+    of 4).  A process reads the switch once, so each form runs in a child; sizes: the tracker's, one with a ragged last group (T = 20
+    -> 100 items) and one that only crop_kernel takes (T = 30)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_pipeline as T
+rs = np.random.RandomState(7)
+H, W = 61, 83
+boxes = [[rs.uniform(-10, W), rs.uniform(-10, H), rs.uniform(2, 60), rs.uniform(2, 60)] for _ in range(12)] + [[W - 3.5, H - 3.5, 3, 3], [0, 0, W, H], [W - 1, H - 1, 1, 1], [-4, -4, 9, 9]]
+frames = rs.randint(0, 256, (len(boxes), H, W, 3)).astype(np.uint8)
+m = T._nat(B=len(boxes))
+for S, factor in ((64, 2.0), (128, 4.0), (256, 4.0), (20, 2.0), (30, 2.0)):
+    crops, rf = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), factor, S, T.MEAN, T.STD)
+    crops, rf = crops.cpu().numpy(), rf.cpu().numpy()
+    for b in range(len(boxes)):
+        want, want_rf = T._host_crop(frames[b], boxes[b], factor, S)
+        assert rf[b] == want_rf and np.array_equal(crops[b], want), (S, boxes[b])
+print("FORM-OK")
+""" % (REPO, os.path.join(REPO, "tests"))
+    env = dict(os.environ, VT_CROP_FAST=form)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "FORM-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
 def test_device_crop_geometry_matches_reference_fixture():
     """vt_crop's crop / pad geometry against the fixtures the REFERENCE's sample_target produced
     (tests/golden/ref_crop_geometry.npz).  With out_size == crop side the fixed-point resize is the
