@@ -248,3 +248,15 @@ def test_form_batch_makes_a_small_batch_run_the_large_batch_forms(geom):
     with pytest.raises(native.VtError, match="vt_graph_capture"):
         small.set_form_batch(256)                    # the captured graph keeps the forms of its capture
     del graph
+
+
+# ViT-Base kernel-form switches (vitb.hip): the default step folds LayerNorm into qkv / fc1 and runs the qkv projection inside the
+# attention kernel; VB_LN_FOLD=0 keeps the separate LayerNorm kernel, VB_FUSED_QKV=0 the qk GEMM + v GEMM + attention kernels,
+# VB_QA_HGROUP the fused kernel's item order.  Every form is held to the reference's golden vectors and stage activations at the
+# default form's tolerances (the child runs tests/test_gpu_vitb.py's golden, stage and batch-invariance tests under the switch).
+@pytest.mark.parametrize("env_kv", ["VB_FUSED_QKV=0", "VB_LN_FOLD=0", "VB_LN_FOLD=0 VB_FUSED_QKV=0", "VB_QA_HGROUP=12", "VB_QA_HGROUP=4"])
+def test_vitb_kernel_form_switches_hold_the_golden_vectors(env_kv):
+    env = dict(os.environ, **dict(kv.split("=") for kv in env_kv.split()))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_vitb.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "golden or each_stage or batch_invariance"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
