@@ -145,6 +145,30 @@ int vt_cal_bbox(vt_model* m, const float* score_dev, const float* size_dev, cons
 int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const double* states_dev, double factor,
             int32_t out_size, const float* mean3, const float* std3, int32_t B, void* stream, float* crops_dev,
             double* resize_factor_dev);
+/* sample_target ALONE (lib/train/data/processing_utils.py:12-79): patch_dev (B,T,T,3) uint8 is the array sample_target returns --
+ * HWC, before Preprocessor.process -- byte for byte (same geometry and fixed-point resize as vt_crop); resize_factor_dev as vt_crop.
+ * A too-small box (processing_utils.py:33-34 raises) writes zeros and a NaN resize factor. */
+int vt_crop_u8(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const double* states_dev, double factor,
+               int32_t out_size, int32_t B, void* stream, uint8_t* patch_dev, double* resize_factor_dev);
+/* Preprocessor.__init__'s mean / std (lib/test/tracker/data_utils.py:8-9) for the uint8 entry points below (default: the ImageNet
+ * values the reference hard-codes).  Preprocessor.process is affine per channel and the stem's first conv is linear, so the
+ * normalisation is folded into that layer's weights in fp64 (here and at vt_load_weights); the conv's zero padding becomes the
+ * byte value that normalises to zero.  Synchronises the device; not capturable; VT_ERR_STATE once graphs have been captured. */
+int vt_set_normalization(vt_model* m, const float* mean3, const float* std3);
+/* Preprocessor.process + OstrackDist.forward on a uint8 search patch (lib/test/tracker/data_utils.py:11-17 +
+ * lib/models/vit_dist/vit_dist.py:77-100): x_patch_dev (B,S,S,3) uint8 as vt_crop_u8 writes it; z_dev (B,3,Tz,Tz) fp32 as in
+ * vt_forward, or NULL after vt_set_template.  Results agree with vt_forward on the normalised fp32 crop to fp32 rounding (the
+ * reference rounds three times per input value, the folded layer once; tests: maps within 1e-5), not bit for bit.
+ * Tuned vit_48 geometries only; VT_ERR_STATE when the stem form this batch selects has no uint8 variant (vt_patch_u8_supported). */
+int vt_forward_u8(vt_model* m, const float* z_dev, const uint8_t* x_patch_dev, int32_t B, void* stream, const vt_outputs* out);
+/* The search rows of vt_stem from a uint8 patch: tokens_dev (B,L,C), rows [len_z, L) written, template rows untouched. */
+int vt_stem_u8(vt_model* m, const uint8_t* x_patch_dev, int32_t B, void* stream, float* tokens_dev);
+/* 1 when a batch of B (under the model's form batch) runs a stem form that reads uint8 patches, else 0. */
+int vt_patch_u8_supported(const vt_model* m, int32_t B);
+/* Which crop kernel form the current device runs (decided once per device by a self test against a byte-load twin):
+ * 1 = the 8-byte unaligned-window form, 2 = the byte-load form, negative = the self test could not run. */
+int vt_crop_form(void);
+
 /* The tail of Vit_dist.track (lib/test/tracker/vit_dist.py:107-111,150-156; clip_box,
  * lib/utils/box_ops.py:97-106): scale the windowed box back to image pixels, map it to the frame,
  * clip with `margin`, and overwrite states_dev (B,4) double in place.  No host sync: a sequence can
@@ -159,11 +183,14 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
                            int32_t search_size, int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev,
                            double* record);
 
-/* The whole per-frame step of Vit_dist.track() (lib/test/tracker/vit_dist.py:87-148) in ONE call: vt_crop of the search region
+/* The whole per-frame step of Vit_dist.track() (lib/test/tracker/vit_dist.py:87-148) in ONE call: the crop of the search region
  * (search_size of the model's config; crops_dev = a (B,3,S,S) float workspace of the caller) -> the network on the cached
- * template (vt_set_template first) -> vt_update_state_record.  Same kernels and results as the three calls; with the
- * small-batch head form the decode kernel runs the tail itself (one launch less per step).  record may be NULL.
- * vit_48 path only. */
+ * template (vt_set_template first) -> vt_update_state_record; with the small-batch head form the decode kernel runs the tail
+ * itself (one launch less per step).  record may be NULL.  vit_48 path only.
+ * Round 6: the crop reaches the stem as sample_target's uint8 patch -- the step is vt_crop_u8 -> vt_forward_u8(z = NULL) ->
+ * vt_update_state_record, bit for bit, and crops_dev holds the (B,S,S,3) uint8 patch in its first bytes -- whenever
+ * vt_patch_u8_supported(m, B) and (mean3, std3) equal the model's normalisation (vt_set_normalization); otherwise (and with
+ * VT_TRACK_U8=0 in the environment at vt_create) it is vt_crop -> vt_forward(z = NULL) -> vt_update_state_record with the fp32 crop. */
 int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, double* states_dev, double factor, const float* mean3,
                   const float* std3, int32_t B, void* stream, float* crops_dev, double* resize_factor_dev, const vt_outputs* out,
                   int32_t margin, double* record);

@@ -35,6 +35,25 @@ def load_case(path):
     return g, sd, z, x
 
 
+def u8_golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "ref_u8_*.npz")))
+
+
+def load_u8_case(path):
+    """(fixture, state dict, z fp32 template crops, uint8 search patches (B,S,S,3)) of a uint8-patch golden file
+    (tests/golden/make_golden_u8.py): the reference model on Preprocessor-normalised patches."""
+    from vittracker_amd import synth
+    g = dict(np.load(path, allow_pickle=False))
+    geom, seed, B = str(g["geom"]), int(g["seed"]), int(g["B"])
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(seed, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    assert synth.state_checksum(sd) == str(g["state_checksum"]), "synth_state_dict drifted from the fixture generator"
+    z, _ = synth.synth_inputs(seed, B, tz, tx)
+    patches = synth.synth_patches(seed, B, tx)
+    assert int(patches.astype(np.uint64).sum()) == int(g["patch_checksum"]), "synth_patches drifted from the fixture generator"
+    return g, sd, z, patches
+
+
 @pytest.fixture(scope="session")
 def native():
     """The C-ABI library (loads everywhere; compute calls need a GPU)."""

@@ -221,11 +221,14 @@ def test_batched_tracker_equals_independent_plugin_trackers():
 
 
 @pytest.mark.parametrize("geom,B", [(128, 3), (256, 2), (128, 200), (256, 180)])
-def test_track_step_equals_its_three_calls(geom, B):
-    """vt_track_step (crop -> network on the cached template -> tail, which the decoding lane of every head form runs itself: the
-    decode kernel on the small-batch path, the fused heads at 200) == vt_crop + vt_forward + vt_update_state_record, bit for bit."""
+def test_track_step_equals_its_three_calls(geom, B, monkeypatch):
+    """vt_track_step with the fp32 crop (VT_TRACK_U8=0, read at vt_create; the default since round 6 hands the stem a uint8 patch:
+    tests/test_gpu_patch_u8.py) -- crop -> network on the cached template -> tail, which the decoding lane of every head form runs
+    itself: the decode kernel on the small-batch path, the fused heads at 200 -- == vt_crop + vt_forward + vt_update_state_record,
+    bit for bit."""
     import torch
     from vittracker_amd import native, synth
+    monkeypatch.setenv("VT_TRACK_U8", "0")
     m = native.Model(geom // 2, geom, max_batch=B)
     m.load_state_dict(synth.synth_state_dict(4, len_z=(geom // 32) ** 2, len_x=(geom // 16) ** 2))
     H, W = 120, 160

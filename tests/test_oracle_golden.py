@@ -60,6 +60,22 @@ def test_torch_oracle_matches_reference(path):
         np.testing.assert_allclose(out[k].numpy(), g[k], atol=TOL, rtol=0, err_msg=k)
 
 
+def test_numpy_oracle_matches_reference_on_uint8_patches():
+    """The reference model on Preprocessor-normalised uint8 patches (tests/golden/make_golden_u8.py): the oracle on the same
+    patches, normalised with the same arithmetic, within the usual fp32 noise -- pins the oracle for the uint8-patch path."""
+    from conftest import load_u8_case, u8_golden_files
+    from vittracker_amd import synth
+    files = u8_golden_files()
+    assert len(files) == 2, "uint8-patch fixtures missing"
+    for path in files:
+        g, sd, z, patches = load_u8_case(path)
+        for recip in (False, True):      # the CPU's true division (how the fixture was made) and the GPU's reciprocal multiply
+            out = onp.forward(sd, z, synth.normalise_patches(patches, reciprocal=recip))
+            for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+                np.testing.assert_allclose(out[k], g[k], atol=TOL, rtol=0, err_msg=f"{k} reciprocal={recip}")
+        assert onp.top2_margin(g["score_map"]).min() > 4e-4
+
+
 def test_clip_box_and_hann_known_answers():
     import os
     from conftest import GOLDEN_DIR

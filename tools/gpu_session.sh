@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box session script (round 5; replaces the one-shot gpu_r4_*.sh family).
 #   gpurun --timeout N -- bash tools/gpu_session.sh <task> [task ...]
-# Every task writes under gpurun_out/s5/<task>/ and prints a short summary.  Tasks:
+# Every task writes under gpurun_out/s6/<task>/ and prints a short summary.  Tasks:
 #   vitb_tests      tests/test_gpu_vitb.py (+ the ViT-Base variants test)
 #   vitb_ab         tools/ab_vitb.py: in-tree library against build_variants/*.so, interleaved, one box
 #   vitb_nofold     the ViT-Base tests and one timing with VB_LN_FOLD=0 (separate LayerNorm kernel)
@@ -15,11 +15,14 @@
 #   race            tools/race_check.py at G128 and G256
 #   trackstep       tracking/track_batch_demo.py --batch 256 at both geometries
 #   generic         tests/test_gpu_generic.py
+#   u8tests         round 6: the uint8-patch path (tests/test_gpu_patch_u8.py) + the tracker-level suites that step through vt_track_step
+#   trackstep_ab    tracking/track_batch_demo.py --batch 256 with the uint8 patch (default) and VT_TRACK_U8=0 (fp32 crop), both geometries, one box
+#   trackprof       rocprofv3 kernel stats of the tracker step (uint8 patch and VT_TRACK_U8=0), both geometries
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 export TMPDIR=/tmp
 for task in "$@"; do
-  O=$R/gpurun_out/s5/$task; rm -rf $O; mkdir -p $O
+  O=$R/gpurun_out/s6/$task; rm -rf $O; mkdir -p $O
   echo "=== $task"
   case $task in
     vitb_tests)
@@ -68,6 +71,27 @@ P
       timeout 600 python tracking/track_batch_demo.py --batch 256 --geom G256 > $O/g256.txt 2>&1; tail -4 $O/g256.txt ;;
     generic)
       timeout 900 python -m pytest tests/test_gpu_generic.py -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -5 $O/pytest.txt ;;
+    u8tests)
+      timeout 1500 python -m pytest tests/test_gpu_patch_u8.py tests/test_gpu_pipeline.py tests/test_gpu_tracker.py tests/test_gpu_harness.py -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -15 $O/pytest.txt ;;
+    trackstep_ab)
+      for g in G128 G256; do for u in 1 0; do
+        VT_TRACK_U8=$u timeout 600 python tracking/track_batch_demo.py --batch 256 --geom $g > $O/${g}_u8_$u.txt 2>&1; echo "--- $g VT_TRACK_U8=$u"; tail -3 $O/${g}_u8_$u.txt
+      done; done ;;
+    trackprof)
+      for g in G128 G256; do for u in 1 0; do
+        rm -rf $O/prof_${g}_$u
+        (cd /tmp && VT_TRACK_U8=$u timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${g}_$u -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 40 --one-stream > $O/prof_${g}_$u.log 2>&1)
+        echo "--- $g VT_TRACK_U8=$u"
+        python3 - $O/prof_${g}_$u <<'P'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/*/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    for r in rows[:7]:
+        print(f"  {r['Name'].split('(')[0].replace('void ','')[:70]:70s} calls {int(r['Calls']):4d}  avg {float(r['AverageNs'])/1e3:7.1f} us  {100*float(r['TotalDurationNs'])/tot:5.1f} %")
+P
+      done; done
+      find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete ;;
     *) echo "unknown task $task" ;;
   esac
 done

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
+    ap.add_argument("--one-stream", action="store_true", help="stop before the two-shard phase (profiling: per-kernel times of ONE step in flight)")
     a = ap.parse_args()
     if a.geom:
         a.config = {"G128": "vit_48_h32_g128", "G256": "vit_48_h32_noKD"}[a.geom]
@@ -76,6 +77,8 @@ def main():
     # Two shards of B sequences, each a BatchedVitTracker of its own (own model workspaces, states and graphs) on its own stream,
     # stepped alternately: the trackers run on the CURRENT stream, so two stream contexts are all it takes.  Kernels of the two
     # shards overlap at their tails and nothing is left of the gap between graph launches.
+    if a.one_stream:
+        return
     bt2 = BatchedVitTracker(p, B)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     trackers = [bt, bt2]

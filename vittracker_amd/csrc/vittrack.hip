@@ -82,6 +82,11 @@ struct vt_model {
     DevBuf stem_w3b;                 // layer 3 as three-piece bf16 images (stem_fused, fp32 build)
     DevBuf stem_w4b;                 // layer 4, the same way: [out tile 3][chunk pair 7][piece 3][64 lanes][8 bf16]
     DevBuf stem_w2k;                 // layer 2 again as [tap][input-channel quad][16 output channels][4] for the 4-block f32 MFMA
+    // layer 1 with Preprocessor.process folded in, for uint8 patches (vt_stem.h: L1In): [162 weights][6 biases][3 pad values]
+    DevBuf stem_w1u;
+    std::vector<double> stem_w1_f64, stem_b1_f64;   // layer 1 with BN folded, kept for vt_set_normalization
+    float norm_mean[3] = {0.485f, 0.456f, 0.406f}, norm_std[3] = {0.229f, 0.224f, 0.225f};   // lib/test/tracker/data_utils.py:8-9
+    int track_u8 = 1;                // VT_TRACK_U8: vt_track_step hands the crop to the stem as a uint8 patch (0: the fp32 crop of vt_crop)
     DevBuf pos_z, pos_x;             // (len, C)
     DevBuf blocks;                   // depth * BLOCK_STRIDE + 2C (final norm)
     DevBuf blocks3;                  // depth * BLOCK3_STRIDE: the MLP's three-piece bf16 images (vt_blocks.h, BF3)
@@ -340,6 +345,34 @@ std::vector<float> hann2d(int F) {
     return w;
 }
 
+// Preprocessor.process folded into layer 1 (vt_stem.h: L1In): x = u / (255 std_c) - mean_c / std_c per channel, so
+// w' = w / (255 std_c), b' = b + sum_{c,tap} w (-mean_c / std_c), in fp64 from the BN-folded weights; pad value 255 mean_c.
+int fold_w1u(vt_model* m, const float* mean3, const float* std3) {
+    const std::vector<double>& w = m->stem_w1_f64;
+    const std::vector<double>& b = m->stem_b1_f64;
+    if (w.size() != 6 * 3 * 9 || b.size() != 6) return fail(VT_ERR_STATE, "layer-1 weights not loaded");
+    std::vector<double> wf(w.size());
+    std::vector<float> img(vts::W1U_FLOATS, 0.f);
+    for (int j = 0; j < 6; ++j) {
+        double bias = b[j];
+        for (int c = 0; c < 3; ++c)
+            for (int t = 0; t < 9; ++t) {
+                const double wv = w[((size_t)j * 3 + c) * 9 + t];
+                wf[((size_t)j * 3 + c) * 9 + t] = wv / (255.0 * (double)std3[c]);
+                bias += wv * (-(double)mean3[c] / (double)std3[c]);
+            }
+        img[vts::W1U_BIAS + j] = (float)bias;
+    }
+    const std::vector<float> sec = pack_conv_sections(wf, 6, 3);
+    std::copy(sec.begin(), sec.end(), img.begin());
+    for (int c = 0; c < 3; ++c) {
+        img[vts::W1U_PAD + c] = (float)(255.0 * (double)mean3[c]);
+        m->norm_mean[c] = mean3[c];
+        m->norm_std[c] = std3[c];
+    }
+    return upload(m->stem_w1u, img);
+}
+
 // ------------------------------------------------------------------------------------- launches
 int check_ready(vt_model* m, int B) {
     if (!m) return fail(VT_ERR_ARG, "null model");
@@ -441,9 +474,28 @@ int gen_head(vt_model* m, const float* feat, int B, hipStream_t st, float* score
     return VT_OK;
 }
 
-int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0, int zmode = 0) {
+// Does the stem form a batch of B (under the model's form batch) selects read uint8 patches?  stem_fused, stem_stream and stem_a do;
+// stem_pipe (G256, f16 build or VT_STEM_STREAM=0 at large batches), the diagnostic builds and the shape-generic kernels do not.
+bool stem_takes_u8(const vt_model* m, int B) {
+    if (m->generic || m->vb || !m->stem_w1u.p) return false;
+    if (m->skip_stem_a != 0 || m->skip_stem_b != 0 || m->dbg_stamps != nullptr) return false;
+    const int Tx = m->cfg.search_size, Tz = m->cfg.template_size, Bf = form_b(m, B);
+    const bool g256 = Tx == 256 && Tz == 128, g128 = Tx == 128 && Tz == 64;
+#ifndef VT_F16
+    if (m->stem_stream < 0 ? (g256 && Bf > 176) : (m->stem_stream != 0 && (g256 || g128))) return true;
+#endif
+    if ((m->stem_fused < 0 ? Bf > 80 : m->stem_fused != 0) && g128) return true;
+    if ((m->stem_pipe < 0 ? Bf > 176 : m->stem_pipe != 0) && g256) return false;
+    return true;       // stem_a + stem_b
+}
+
+int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0, int zmode = 0, bool xu8 = false) {
     // f0: first frame of this slice in the model workspace (z, x, tokens already point at the slice)
     // zmode 0: both crops; 1: search crop only (template token rows already in `tokens`); 2: template crop only
+    // xu8: x is a uint8 (B, Tx, Tx, 3) patch (vt_crop_u8) and layer 1 runs on the folded weights w1u; zmode 1 only
+    if (xu8 && (zmode != 1 || !stem_takes_u8(m, B))) return fail(VT_ERR_STATE, "this stem form has no uint8-patch variant");
+    const float* const w1 = xu8 ? m->stem_w1u.p : m->stem_w[0].p;
+    const float* const b1 = xu8 ? m->stem_w1u.p + vts::W1U_BIAS : m->stem_b[0].p;
     if (m->generic) return gen_stem(m, z, x, B, st, tokens, zmode);
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
@@ -470,18 +522,20 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         const bool diag = m->skip_stem_a != 0 || m->skip_stem_b != 0 || m->dbg_stamps != nullptr;
         if (want_stream && !diag && (g256 || g128)) {
             auto go = [&](auto kernel, size_t lds) {
-                hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds, st, z, x, m->stem_w[0].p, m->stem_b[0].p, m->stem_b[1].p,
+                hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds, st, z, x, w1, b1, m->stem_b[1].p,
                                    m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p, m->pos_z.p, m->pos_x.p, tokens, m->L,
                                    m->len_z, m->stem_w2k.p);
             };
             if (g256) {
                 constexpr size_t lds = vts::StreamGeo<256, 128>::LDS_BYTES;
-                if (zmode == 0) go(&vts::stem_stream_kernel<256, 128, 0>, lds);
+                if (xu8) go(&vts::stem_stream_kernel<256, 128, 1, true>, lds);
+                else if (zmode == 0) go(&vts::stem_stream_kernel<256, 128, 0>, lds);
                 else if (zmode == 1) go(&vts::stem_stream_kernel<256, 128, 1>, lds);
                 else go(&vts::stem_stream_kernel<256, 128, 2>, lds);
             } else {
                 constexpr size_t lds = vts::StreamGeo<128, 64>::LDS_BYTES;
-                if (zmode == 0) go(&vts::stem_stream_kernel<128, 64, 0>, lds);
+                if (xu8) go(&vts::stem_stream_kernel<128, 64, 1, true>, lds);
+                else if (zmode == 0) go(&vts::stem_stream_kernel<128, 64, 0>, lds);
                 else if (zmode == 1) go(&vts::stem_stream_kernel<128, 64, 1>, lds);
                 else go(&vts::stem_stream_kernel<128, 64, 2>, lds);
             }
@@ -496,13 +550,16 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         // whole patch embedding of a frame in one workgroup; only token rows leave the CU
         const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES_P, st, z, x, m->stem_w[0].p, m->stem_b[0].p,
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), vts::FusedGeo::LDS_BYTES_P, st, z, x, w1, b1,
                                m->stem_w[1].p, m->stem_b[1].p, m->stem_w[2].p, m->stem_b[2].p, m->stem_w[3].p, m->stem_b[3].p,
                                m->pos_z.p, m->pos_x.p, tokens, m->L, m->len_z, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p, m->stem_w3b.p, m->stem_w4b.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_fused_kernel<0, true>);
-        else if (!m->stem_bf3) {      // VT_STEM_BF3=0: layer 3 on fp32 MFMAs (the all-fp32-MFMA step bench.py reports beside the default)
+        else if (xu8) {
+            if (m->stem_bf3) go(&vts::stem_fused_kernel<1, false, true, true>);
+            else go(&vts::stem_fused_kernel<1, false, false, true>);
+        } else if (!m->stem_bf3) {      // VT_STEM_BF3=0: layer 3 on fp32 MFMAs (the all-fp32-MFMA step bench.py reports beside the default)
             if (zmode == 0) go(&vts::stem_fused_kernel<0, false, false>);
             else if (zmode == 1) go(&vts::stem_fused_kernel<1, false, false>);
             else go(&vts::stem_fused_kernel<2, false, false>);
@@ -544,8 +601,12 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
                            m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
     } else {
         const size_t lds_a = sizeof(float) * std::max(vts::stem_a_lds_floats(Tx, px.r2), vts::stem_a_lds_floats(Tz, pz.r2));
-        hipLaunchKernelGGL(vts::stem_a_kernel, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
-                           m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
+        if (xu8)
+            hipLaunchKernelGGL(vts::stem_a_kernel<true>, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, w1, b1, m->stem_w[1].p,
+                               m->stem_b[1].p, m->skip_stem_a);
+        else
+            hipLaunchKernelGGL(vts::stem_a_kernel<false>, dim3(B * (ax.bands + az.bands)), dim3(256), lds_a, st, ax, az, m->stem_w[0].p,
+                               m->stem_b[0].p, m->stem_w[1].p, m->stem_b[1].p, m->skip_stem_a);
     }
     HIP_TRY(hipGetLastError());
     vts::CropB bx{act_x, m->pos_x.p, Tx / 4, px.r4, zmode == 2 ? 0 : (Tx / 16) / px.r4, m->len_z};
@@ -844,14 +905,22 @@ constexpr int CROP_MAX_DEVICES = 64;
 int g_crop_bytes[CROP_MAX_DEVICES];        // 0: not tested yet, 1: fast form, 2: byte-load form
 std::mutex g_crop_mutex;
 
+// u8out: `crops` is a uint8 (B, T, T, 3) patch buffer (sample_target's output; mean3 / std3 unused) instead of the fp32 (B, 3, T, T) crop
 void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const double* states, double factor, int T, const float* mean3,
-                 const float* std3, int B, hipStream_t st, float* crops, double* rf) {
+                 const float* std3, int B, hipStream_t st, float* crops, double* rf, bool u8out = false) {
     static const int fast = [] { const char* v = std::getenv("VT_CROP_FAST"); return v && *v ? std::atoi(v) : 1; }();     // groups per workgroup (1, 2, 4); 0: crop_kernel
+    static const float none3[3] = {0.f, 1.f, 1.f};
+    if (u8out) mean3 = std3 = none3;
     if (!bytes && fast > 0 && (T & 3) == 0 && T <= vtt::CROP_FAST_MAX_T) {
         const int ngroups = (T * (T / 4) + 255) / 256;
+        if (u8out) {
+            hipLaunchKernelGGL((vtt::crop_fast_kernel<1, true>), dim3(ngroups, B), dim3(256), 0, st, frames, H, W, states, factor, T, 0.f, 0.f, 0.f, 1.f,
+                               1.f, 1.f, crops, rf);
+            return;
+        }
         auto go = [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL(vtt::crop_fast_kernel<G>, dim3((ngroups + G - 1) / G, B), dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0],
+            hipLaunchKernelGGL((vtt::crop_fast_kernel<G, false>), dim3((ngroups + G - 1) / G, B), dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0],
                                mean3[1], mean3[2], std3[0], std3[1], std3[2], crops, rf);
         };
         if (fast >= 4 && ngroups >= 4) go(std::integral_constant<int, 4>{});
@@ -860,6 +929,13 @@ void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const do
         return;
     }
     dim3 grid((T * ((T + 3) / 4) + 255) / 256, B);
+    if (u8out) {
+        if (bytes)
+            hipLaunchKernelGGL((vtt::crop_kernel<true, true>), grid, dim3(256), 0, st, frames, H, W, states, factor, T, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, crops, rf);
+        else
+            hipLaunchKernelGGL((vtt::crop_kernel<false, true>), grid, dim3(256), 0, st, frames, H, W, states, factor, T, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, crops, rf);
+        return;
+    }
     if (bytes)
         hipLaunchKernelGGL(vtt::crop_kernel<true>, grid, dim3(256), 0, st, frames, H, W, states, factor, T, mean3[0], mean3[1], mean3[2],
                            std3[0], std3[1], std3[2], crops, rf);
@@ -1002,7 +1078,11 @@ static hipError_t allow_stem_lds() {
     allow(&vts::stem_fused_kernel<0, false, false>, lf);
     allow(&vts::stem_fused_kernel<1, false, false>, lf);
     allow(&vts::stem_fused_kernel<2, false, false>, lf);
+    allow(&vts::stem_fused_kernel<1, false, true, true>, lf);
+    allow(&vts::stem_fused_kernel<1, false, false, true>, lf);
 #ifndef VT_F16
+    allow(&vts::stem_stream_kernel<256, 128, 1, true>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
+    allow(&vts::stem_stream_kernel<128, 64, 1, true>, (int)vts::StreamGeo<128, 64>::LDS_BYTES);
     allow(&vts::stem_stream_kernel<256, 128, 0>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
     allow(&vts::stem_stream_kernel<256, 128, 1>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
     allow(&vts::stem_stream_kernel<256, 128, 2>, (int)vts::StreamGeo<256, 128>::LDS_BYTES);
@@ -1111,6 +1191,7 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     m->head_split = env_int("VT_HEAD_SPLIT", -1);
     m->stem_fuse = env_int("VT_STEM_FUSE", cfg->search_size == 128 ? 1 : 0);
     m->stem_bf3 = env_int("VT_STEM_BF3", 1);
+    m->track_u8 = env_int("VT_TRACK_U8", 1);
     if (!generic) {
         const StemPlan sx = stem_plan(cfg->search_size), sz = stem_plan(cfg->template_size);
         m->plan_r2[0] = sx.r2; m->plan_r4[0] = sx.r4; m->plan_r2[1] = sz.r2; m->plan_r4[1] = sz.r4;
@@ -1234,6 +1315,7 @@ void vt_destroy(vt_model* m) {
     if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
+    m->stem_w1u.release();
     m->stem_w3b.release();
     m->stem_w4b.release();
     m->act_x.release(); m->act_z.release();
@@ -1280,6 +1362,9 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         if (i < 1) {   // VALU layer: [r][cin][s][cout] sections, weights become scalar operands
             if ((rc = upload(m->stem_w[i], pack_conv_sections(w, STEM_CH[i + 1], STEM_CH[i])))) return rc;
             if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+            m->stem_w1_f64 = w;
+            m->stem_b1_f64 = b;
+            if ((rc = fold_w1u(m, m->norm_mean, m->norm_std))) return rc;      // the uint8-patch form of layer 1
         } else {       // MFMA layers: A-operand images, bias padded to whole 16-channel tiles
             const int tiles = (STEM_CH[i + 1] + 15) / 16, nch = (9 * ((STEM_CH[i] + 3) / 4) + 3) / 4;
             std::vector<float> img((size_t)tiles * nch * 256), bias((size_t)tiles * 16, 0.f);
@@ -1585,6 +1670,81 @@ int vt_crop(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const 
     return VT_OK;
 }
 
+int vt_crop_u8(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, const double* states_dev, double factor,
+               int32_t out_size, int32_t B, void* stream, uint8_t* patch_dev, double* resize_factor_dev) {
+    if (!m || !frames_dev || !states_dev || !patch_dev || !resize_factor_dev) return fail(VT_ERR_ARG, "null argument");
+    if (B < 1 || H < 1 || W < 1 || out_size < 1 || !(factor > 0.0)) return fail(VT_ERR_ARG, "bad crop arguments");
+    bool crop_bytes = false;
+    if (int rcs = crop_selftest(&crop_bytes)) return rcs;
+    launch_crop(crop_bytes, frames_dev, H, W, states_dev, factor, out_size, nullptr, nullptr, B, static_cast<hipStream_t>(stream),
+                reinterpret_cast<float*>(patch_dev), resize_factor_dev, true);
+    HIP_TRY(hipGetLastError());
+    return VT_OK;
+}
+
+int vt_set_normalization(vt_model* m, const float* mean3, const float* std3) {
+    if (!m || !mean3 || !std3) return fail(VT_ERR_ARG, "null argument");
+    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    for (int c = 0; c < 3; ++c)
+        if (!(std3[c] > 0.f) || !std::isfinite(mean3[c]) || !std::isfinite(std3[c])) return fail(VT_ERR_ARG, "bad mean / std");
+    if (m->graphs_captured > 0 && (std::memcmp(mean3, m->norm_mean, 12) != 0 || std::memcmp(std3, m->norm_std, 12) != 0))
+        return fail(VT_ERR_STATE, "captured graphs read the folded layer-1 weights: set the normalisation before capturing");
+    if (!m->weights_loaded) {      // remembered; vt_load_weights folds with these
+        std::memcpy(m->norm_mean, mean3, 12);
+        std::memcpy(m->norm_std, std3, 12);
+        return VT_OK;
+    }
+    HIP_TRY(hipDeviceSynchronize());      // no step may be reading the image that is about to be replaced
+    return fold_w1u(m, mean3, std3);
+}
+
+int vt_patch_u8_supported(const vt_model* m, int32_t B) {
+    if (!m) return 0;
+    return stem_takes_u8(m, B) ? 1 : 0;
+}
+
+int vt_crop_form(void) {
+    bool bytes = false;
+    if (crop_selftest(&bytes)) return -1;
+    return bytes ? 2 : 1;
+}
+
+// Does (mean3, std3) equal the normalisation folded into the uint8 form of layer 1?
+static bool same_norm(const vt_model* m, const float* mean3, const float* std3) {
+    return std::memcmp(mean3, m->norm_mean, 12) == 0 && std::memcmp(std3, m->norm_std, 12) == 0;
+}
+
+int vt_stem_u8(vt_model* m, const uint8_t* x_patch_dev, int32_t B, void* stream, float* tokens_dev) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!x_patch_dev || !tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    return run_stem(m, nullptr, reinterpret_cast<const float*>(x_patch_dev), B, static_cast<hipStream_t>(stream), tokens_dev, 0, 1, true);
+}
+
+int vt_forward_u8(vt_model* m, const float* z_dev, const uint8_t* x_patch_dev, int32_t B, void* stream, const vt_outputs* out) {
+    int rc = check_ready(m, B);
+    if (rc) return rc;
+    if (!x_patch_dev) return fail(VT_ERR_ARG, "null device pointer");
+    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* const xu = reinterpret_cast<const float*>(x_patch_dev);
+    if (!z_dev) {     // cached template: the tracker step's network part
+        if (m->tmpl_frames < B)
+            return fail(VT_ERR_STATE, "vt_forward_u8 with a null template needs vt_set_template for at least " + std::to_string(B) + " frames first");
+        if (m->tmpl_form_batch != m->form_batch)
+            return fail(VT_ERR_STATE, "the template cache was written under another form batch: call vt_set_template again after vt_set_form_batch");
+        if ((rc = run_stem(m, nullptr, xu, B, st, m->tokens_c.p, 0, 1, true))) return rc;
+        if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
+        return run_head(m, m->feat.p, B, st, out);
+    }
+    // a template given with the call: its rows from the fp32 crop, the search rows from the patch, then the uncached blocks
+    if ((rc = run_stem(m, z_dev, nullptr, B, st, m->tokens.p, 0, 2))) return rc;
+    if ((rc = run_stem(m, nullptr, xu, B, st, m->tokens.p, 0, 1, true))) return rc;
+    if ((rc = run_blocks(m, m->tokens.p, B, -1, st, m->feat.p, nullptr))) return rc;
+    return run_head(m, m->feat.p, B, st, out);
+}
+
 int vt_update_state(vt_model* m, const float* hann_boxes_dev, const double* resize_factor_dev, int32_t search_size,
                     int32_t H, int32_t W, int32_t margin, int32_t B, void* stream, double* states_dev) {
     if (!m || !hann_boxes_dev || !resize_factor_dev || !states_dev || B < 1) return fail(VT_ERR_ARG, "bad argument");
@@ -1614,10 +1774,16 @@ int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, doub
         return fail(VT_ERR_STATE, "vt_track_step needs vt_set_template for at least " + std::to_string(B) + " frames first");
     if (m->tmpl_form_batch != m->form_batch)
         return fail(VT_ERR_STATE, "the template cache was written under another form batch: call vt_set_template again after vt_set_form_batch");
-    if (!states_dev) return fail(VT_ERR_ARG, "null argument");
-    if ((rc = vt_crop(m, frames, H, W, states_dev, factor, m->cfg.search_size, mean3, std3, B, stream, crops_dev, resize_factor_dev))) return rc;
+    if (!states_dev || !mean3 || !std3 || !crops_dev) return fail(VT_ERR_ARG, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((rc = run_stem(m, nullptr, crops_dev, B, st, m->tokens_c.p, 0, 1))) return rc;
+    // The crop reaches the stem as the uint8 patch sample_target returns (a quarter of the fp32 crop's bytes, written and read once)
+    // whenever the stem form of this batch reads patches and (mean3, std3) is the normalisation folded into its layer 1; else as the
+    // fp32 crop of vt_crop.  Either way crops_dev is the workspace: the patch occupies its first B * S * S * 3 bytes.
+    const bool u8 = m->track_u8 != 0 && stem_takes_u8(m, B) && same_norm(m, mean3, std3);
+    if (u8) {
+        if ((rc = vt_crop_u8(m, frames, H, W, states_dev, factor, m->cfg.search_size, B, stream, reinterpret_cast<uint8_t*>(crops_dev), resize_factor_dev))) return rc;
+    } else if ((rc = vt_crop(m, frames, H, W, states_dev, factor, m->cfg.search_size, mean3, std3, B, stream, crops_dev, resize_factor_dev))) return rc;
+    if ((rc = run_stem(m, nullptr, crops_dev, B, st, m->tokens_c.p, 0, 1, u8))) return rc;
     if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
     const TrackTail tail{resize_factor_dev, states_dev, record, m->cfg.search_size, H, W, margin};
     return run_head(m, m->feat.p, B, st, out, 0, &tail);

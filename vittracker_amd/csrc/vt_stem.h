@@ -83,8 +83,41 @@ __device__ __forceinline__ void load_section(float (&w)[N], const float* base, i
 #define VT_STEM_A_WAVES_PER_SIMD 4
 #endif
 
+// value of the previous lane (lane 0: 0) in VALU latency: v_mov_b32_dpp wave_shr:1
+// (v_mov_b32_dpp with no `old` operand: lanes without a source -- lane 0 -- read 0; with update_dpp's `old` hipcc initialises the
+// destination with a v_mov in front of every call)
+__device__ __forceinline__ float lane_left(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+
+// ---- layer 1's two input forms ------------------------------------------------------------------------------------------------
+// A layer-1 thread consumes input rows 2 p1 - 1 .. 2 p1 + 1 x columns 4 qp .. 4 qp + 3 x 3 channels.
+//   fp32 form (U8 = false): the normalised NCHW crop Preprocessor.process produces (lib/test/tracker/data_utils.py:11-17) -- nine
+//     float4, one per (row, channel).
+//   uint8 form (U8 = true; round 6): the (T, T, 3) uint8 patch exactly as sample_target returns it
+//     (lib/train/data/processing_utils.py:68-79; vt_crop_u8 writes it).  A row's four pixels are 12 consecutive bytes = ONE
+//     buffer_load_dwordx3 per row: 3 loads and 9 registers per thread instead of 9 and 36, a quarter of the bytes.
+//     Preprocessor.process is affine per channel, x = a_c u + b_c with a_c = 1 / (255 std_c), b_c = -mean_c / std_c, and layer 1
+//     is linear in x, so it is folded into the layer's weights (fp64, vt_load_weights / vt_set_normalization):
+//         w1u = [r][c][s][6] sections of w a_c  |  6 biases b1 + sum_taps w b_c  |  3 pad values 255 mean_c
+//     The conv's zero padding is zero in the NORMALISED domain, i.e. the byte value u where a_c u + b_c = 0: taps left of / above
+//     the crop substitute 255 mean_c.  (The crop's own zero padding -- the part of the window outside the frame -- is ordinary
+//     uint8 zeros inside the patch, as in the reference.)  Against the three separately rounded fp32 operations of the reference
+//     this changes a layer-1 sum by a few 1e-7 (tests: maps within 1e-5 of vt_crop + vt_forward and of the reference vectors).
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+template <bool U8> struct L1In { f4 v[3][3]; };
+template <> struct L1In<true> { u3v v[3]; };
+constexpr int W1U_BIAS = 162, W1U_PAD = 168, W1U_FLOATS = 176;      // offsets inside w1u (floats)
+// channel c of the row's four pixels: byte 3 k + c of the 12-byte group; each conversion is one v_cvt_f32_ubyteN
+__device__ __forceinline__ f4 l1_channel(const u3v& d, int c) {
+    auto ub = [&](int i) { return (float)((d[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+    return f4{ub(c), ub(3 + c), ub(6 + c), ub(9 + c)};
+}
+
 // w1g: [r][c][s][6] scalar sections (layer 1, VALU); w2img: [1][5][64][4] MFMA image of layer 2 with
 // the input channels padded 6 -> 8; b2: 16 (12 used).
+// U8: the crops are uint8 (T, T, 3) patches, w1g / b1 point into the folded image w1u (see L1In above).
+template <bool U8 = false>
 __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
     CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, int skip) {   // skip: phase-timing diagnostic, 0 in production
@@ -108,7 +141,7 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
     // thread, software-pipelined over passes of 256 pixel pairs: the nine 16-byte row fetches of the
     // next pass are in flight while the current pass is computed.
     const int npairs = NR1 * HALF;
-    auto fetch = [&](int i, f4 (&v)[3][3]) {
+    auto fetch = [&](int i, L1In<U8>& v) {
         i = i < npairs ? i : npairs - 1;            // clamped lanes recompute the last pair
         const int lr = i / HALF, qp = i - lr * HALF;
         const int p1 = 2 * p0 - 1 + lr;
@@ -117,12 +150,18 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
             int iy = 2 * p1 + r - 1;                // < 0 only for r = 0 at the image top (and for
             const float keep = iy >= 0 ? 1.f : 0.f; // the padding row p1 = -1): branch-free zeroing
             iy = iy >= 0 ? iy : 0;
+            if constexpr (U8) {                     // the row's 12 bytes; a padding row is replaced in compute()
+                typedef unsigned u3a __attribute__((ext_vector_type(3), aligned(4)));
+                const u3a t = *reinterpret_cast<const u3a*>(reinterpret_cast<const unsigned char*>(in) + (((size_t)b * T + iy) * T + 4 * qp) * 3);
+                v.v[r] = u3v{t.x, t.y, t.z};
+            } else {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                v[r][c] = ld4(in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp) * splat4(keep);
+                for (int c = 0; c < 3; ++c)
+                    v.v[r][c] = ld4(in + (((size_t)b * 3 + c) * T + iy) * T + 4 * qp) * splat4(keep);
+            }
         }
     };
-    auto compute = [&](int i, const f4 (&v)[3][3]) {
+    auto compute = [&](int i, const L1In<U8>& v) {
         const bool in_range = i < npairs;           // clamped lanes compute (keeps shuffles whole) but do not store
         i = in_range ? i : npairs - 1;
         const int lr = i / HALF, qp = i - lr * HALF;
@@ -138,9 +177,18 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
             float (&nxt)[18] = (sec & 1) ? wa : wb;
             if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
             const int r = sec / 3, c = sec % 3;
-            // column 4*qp-1 is the previous lane's .w (same image row); 0 left of the image
-            const float left = __shfl_up(v[r][c].w, 1, 64);
-            const float t0[3] = {qp > 0 ? left : 0.f, v[r][c].x, v[r][c].y}, t1[3] = {v[r][c].y, v[r][c].z, v[r][c].w};
+            f4 vv;
+            float padv = 0.f;                       // what a tap outside the crop reads (fp32 form: the zero padding itself)
+            if constexpr (U8) {
+                padv = b1[W1U_PAD - W1U_BIAS + c];
+                vv = l1_channel(v.v[r], c);
+                if (2 * p1 + r - 1 < 0) vv = splat4(padv);
+            } else {
+                vv = v.v[r][c];
+            }
+            // column 4*qp-1 is the previous lane's .w (same image row); the padding left of the image
+            const float left = __shfl_up(vv.w, 1, 64);
+            const float t0[3] = {qp > 0 ? left : padv, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -161,16 +209,13 @@ __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a_kernel(
         }
     };
     if (!(skip & 1)) {
-        f4 va[3][3], vb[3][3];
+        L1In<U8> va, vb;
         fetch(threadIdx.x, va);
         for (int base = 0; base + (int)(threadIdx.x & ~63) < npairs; base += 256) {   // whole waves drop out
             const int i = base + threadIdx.x;
             if (base + 256 + (int)(threadIdx.x & ~63) < npairs) fetch(i + 256, vb);   // next pass in flight
             compute(i, va);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) va[r][c] = vb[r][c];
+            va = vb;
         }
     }
     f4 w2a[5][1];                                // layer-2 weights: in flight across the barrier below
@@ -236,13 +281,6 @@ __device__ __forceinline__ JobA make_job_a(const CropA& c, int b, int k, int map
     j.out = c.out + (size_t)b * (c.T >> 2) * (c.T >> 2) * 12;
     return j;
 }
-// value of the previous lane (lane 0: 0) in VALU latency: v_mov_b32_dpp wave_shr:1
-// (v_mov_b32_dpp with no `old` operand: lanes without a source -- lane 0 -- read 0; with update_dpp's `old` hipcc initialises the
-// destination with a v_mov in front of every call)
-__device__ __forceinline__ float lane_left(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
-}
-
 __global__ __launch_bounds__(256, VT_STEM_A_WAVES_PER_SIMD) void stem_a2_kernel(
     CropA cx, CropA cz, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, int skip) {

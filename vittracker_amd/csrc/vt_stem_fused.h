@@ -94,7 +94,10 @@ struct BandF {
 // run-time conditions they put every band's prefetched registers through a copy at each conditional call.
 // L3B (fp32 build; VT_STEM_BF3, default 1): layer 3 as exact three-piece bf16 products; false = on fp32 MFMAs, the form the f16 build
 // always runs (on its own MFMA).
-template <int ZMODE, bool DIAG, bool L3B = true>
+// U8 (round 6; ZMODE 1 only -- the tracker step, whose template is cached): `xin` is the uint8 (B, 128, 128, 3) patch vt_crop_u8 wrote
+// (sample_target's own output), w1g / b1 point into the folded layer-1 image w1u (vt_stem.h: L1In).  A band's fetch is 3 loads of
+// 12 bytes per thread instead of 9 of 16: a quarter of the bytes the first interval waits for.
+template <int ZMODE, bool DIAG, bool L3B = true, bool U8 = false>
 __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin,                       // (B,3,64,64), (B,3,128,128)
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ w2img, const float* __restrict__ b2,
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     const float* __restrict__ w3b,                 // layer-3 weights as three-piece bf16 images [out tile 2][chunk pair 4][piece 3][64 lanes][8 bf16] (f32 build)
     const float* __restrict__ w4b) {               // layer-4 weights, the same way: [out tile 3][chunk pair 7][piece 3][64 lanes][8 bf16]
     using G = FusedGeo;
+    static_assert(!U8 || ZMODE == 1, "the uint8 patch form is the search-only (cached template) step");
     constexpr bool L3BF3 = L3B && !VT_IS_F16;
     constexpr bool do_z = ZMODE != 1, do_x = ZMODE != 2;
     const int skip = DIAG ? skip_arg : 0;
@@ -134,7 +138,8 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
 
     // bands of this frame: group A = {z, x1, x3}, group B = {x0, x2}
     const float* const zin_b = zin + (size_t)b * 3 * G::TZ * G::TZ;
-    const float* const xin_b = xin + (size_t)b * 3 * G::TX * G::TX;
+    const float* const xin_b = U8 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(xin) + (size_t)b * 3 * G::TX * G::TX)
+                                  : xin + (size_t)b * 3 * G::TX * G::TX;
     const BandF<true, 0> bz{zin_b};
     const BandF<false, 0> bx0{xin_b};
     const BandF<false, 1> bx1{xin_b};
@@ -152,12 +157,21 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     // Buffer loads (scalar descriptor + one 32-bit offset VGPR; kernel rows 1 and 2 are immediate offsets of the same register,
     // the channel plane is the scalar offset): a fetch holds 2 address registers instead of 9 64-bit pairs.
     const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin_b), 0, 3 * G::TZ * G::TZ * 4, 0x00020000);
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin_b), 0, 3 * G::TX * G::TX * 4, 0x00020000);
-    auto fetch = [&](const auto& J, f4 (&v)[3][3]) {
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin_b), 0, 3 * G::TX * G::TX * (U8 ? 1 : 4), 0x00020000);
+    auto fetch = [&](const auto& J, L1In<U8>& vin) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const int pair = fresh(pair_);
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const int p1 = 2 * J.p0 - 1 + lr;                    // layer-1 row (>= 0)
+        if constexpr (U8) {     // the uint8 patch: row y, pixels 4 qp .. 4 qp + 3 = bytes 12 (y T / 4 + qp) .. + 11, one load per kernel row
+            const unsigned o1 = 12u * ((((unsigned)(2 * p1)) << (J.lgT - 2)) + (unsigned)qp);
+            const unsigned o0 = p1 > 0 ? o1 - (3u << J.lgT) : o1;                              // the image top reads row 0 (replaced in layer1)
+            vin.v[0] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o0, 0, 0);
+            vin.v[1] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1, 0, 0);
+            vin.v[2] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1 + (3u << J.lgT), 0, 0);
+            return;
+        } else {
+        auto& v = vin.v;
         const unsigned off1 = ((((unsigned)(2 * p1)) << J.lgT) + 4u * (unsigned)qp) << 2;      // input row 2 p1 (kernel row 1), bytes
         const unsigned off0 = p1 > 0 ? off1 - (4u << J.lgT) : off1;                            // row 2 p1 - 1; the image top reads row 0 (zeroed in layer1)
 #pragma unroll
@@ -168,8 +182,9 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
                                                                    c << (2 * J.lgT + 2), 0);
                 v[r][c] = __builtin_bit_cast(f4, t);
             }
+        }
     };
-    auto layer1 = [&](const auto& J, const f4 (&v)[3][3]) {
+    auto layer1 = [&](const auto& J, const L1In<U8>& vin) {
         // layer 1 is the long pole of an interval (VALU-bound); without this the issue arbiter favours the
         // older group whatever it is doing, and the younger group's layer 1 takes three times as long
         __builtin_amdgcn_s_setprio(3);
@@ -197,9 +212,17 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             float (&nxt)[18] = (sec & 1) ? wa : wb;
             if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
             const int r = sec / 3, c = sec % 3;
-            const f4 vv = (r == 0 && J.p0 == 0) ? v[r][c] * splat4(keep0) : v[r][c];     // kernel row 0 is the zero padding only in the band at the image top
+            f4 vv;
+            float padv = 0.f;                                 // what a tap outside the crop reads (fp32 form: the zero padding itself)
+            if constexpr (U8) {
+                padv = b1[W1U_PAD - W1U_BIAS + c];            // 255 mean_c: normalises to zero
+                vv = l1_channel(vin.v[r], c);
+                if (r == 0 && J.p0 == 0 && keep0 == 0.f) vv = splat4(padv);
+            } else {
+                vv = (r == 0 && J.p0 == 0) ? vin.v[r][c] * splat4(keep0) : vin.v[r][c];     // kernel row 0 is the zero padding only in the band at the image top
+            }
             const float left = lane_left(vv.w);               // a wave starts at a row start: lane 0 has qp = 0
-            const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
+            const float t0[3] = {qp > 0 ? left : padv, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -309,7 +332,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     // crop, which the first interval computes on, (3) group B's first band, needed one interval later.  The constant's load is
     // older than the crop fetch, so the LDS write below waits for it alone (counted vmcnt); issued after the fetch it sat behind
     // 26 MB of crop requests from all workgroups (a 5-8 k cycle prologue).
-    f4 v[3][3];
+    L1In<U8> v;
     const int t = threadIdx.x;
 #ifndef VT_F16
     constexpr int NW2 = 9 * 32;                              // [tap][2][16][4] floats: layer-2 weights for the 4-block MFMA

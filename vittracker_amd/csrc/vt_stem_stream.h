@@ -62,7 +62,9 @@ struct StreamGeo {
 };
 
 // ZMODE 0: both crops; 1: search bands only (the template's token rows are cached in `tokens`); 2: template bands only.
-template <int TX, int TZ, int ZMODE>
+// U8 (round 6; ZMODE 1 only): `xin` is the uint8 (B, TX, TX, 3) patch of vt_crop_u8, w1g / b1 point into the folded layer-1 image
+// w1u (vt_stem.h: L1In) -- the layer-1 waves hold 2 x 9 instead of 2 x 36 prefetch registers and fetch a quarter of the bytes.
+template <int TX, int TZ, int ZMODE, bool U8 = false>
 __global__ __launch_bounds__(1024) void stem_stream_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin,                       // (B,3,TZ,TZ), (B,3,TX,TX)
     const float* __restrict__ w1g, const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ w3img,
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
     const float* __restrict__ pos_x, float* __restrict__ tokens, int L, int len_z,
     const float* __restrict__ w2k) {               // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4]
     using G = StreamGeo<TX, TZ>;
+    static_assert(!U8 || ZMODE == 1, "the uint8 patch form is the search-only (cached template) step");
     constexpr int g_lo = ZMODE == 1 ? G::NBZ : 0, g_hi = ZMODE == 2 ? G::NBZ : G::NB;   // bands [g_lo, g_hi)
     constexpr int NIV = g_hi - g_lo + 3, NIV2 = (NIV + 1) / 2;                         // intervals; the loops run two per iteration
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -142,12 +145,22 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
         // =============================================================== layer 1: waves 0-7 =====================================
         const int pair_ = wave * 64 + lane;                      // this thread's pixel pair of a band (0..511)
         const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin + (size_t)b * 3 * TZ * TZ), 0, 3 * TZ * TZ * 4, 0x00020000);
-        const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX * 4, 0x00020000);
-        auto fetch = [&](const Band& J, f4 (&v)[3][3]) {           // raw loads only: nothing here depends on the loaded data
+        const auto rsrc_x = U8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(xin) + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX, 0x00020000)
+                               : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX * 4, 0x00020000);
+        auto fetch = [&](const Band& J, L1In<U8>& vin) {           // raw loads only: nothing here depends on the loaded data
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const int pair = fresh(pair_);
             const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
             const int p1 = 2 * J.kb * J.R2 - 1 + lr;               // layer-1 row (>= 0)
+            if constexpr (U8) {     // row y, pixels 4 qp .. 4 qp + 3 of the uint8 patch = bytes 12 (y T / 4 + qp) .. + 11: one load per kernel row
+                const unsigned o1 = 12u * ((((unsigned)(2 * p1)) << (J.lgT - 2)) + (unsigned)qp);
+                const unsigned o0 = p1 > 0 ? o1 - (3u << J.lgT) : o1;                              // the image top reads row 0 (replaced in layer1)
+                vin.v[0] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o0, 0, 0);
+                vin.v[1] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1, 0, 0);
+                vin.v[2] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1 + (3u << J.lgT), 0, 0);
+                return;
+            } else {
+            auto& v = vin.v;
             const unsigned off1 = ((((unsigned)(2 * p1)) << J.lgT) + 4u * (unsigned)qp) << 2;
             const unsigned off0 = p1 > 0 ? off1 - (4u << J.lgT) : off1;   // the image top reads row 0 (zeroed in layer1)
             const unsigned off2 = off1 + (4u << J.lgT);
@@ -159,8 +172,9 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
                     const u4 t = J.is_z ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo, so, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, so, 0);
                     v[r][c] = __builtin_bit_cast(f4, t);
                 }
+            }
         };
-        auto layer1 = [&](const Band& J, int g, const f4 (&v)[3][3]) {
+        auto layer1 = [&](const Band& J, int g, const L1In<U8>& vin) {
             f4* const ring = ring0 + (g & 1) * G::RING;
             const f4* const other_ring = ring0 + ((g & 1) ^ 1) * G::RING;
             const int pair = fresh(pair_);
@@ -186,9 +200,17 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
                 float (&nxt)[18] = (sec & 1) ? wa : wb;
                 if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
                 const int r = sec / 3, c = sec % 3;
-                const f4 vv = (r == 0 && J.kb == 0) ? v[r][c] * splat4(keep0) : v[r][c];      // only the band at the top of a crop has a padding row
+                f4 vv;
+                float padv = 0.f;                                   // what a tap outside the crop reads (fp32 form: the zero padding itself)
+                if constexpr (U8) {
+                    padv = b1[W1U_PAD - W1U_BIAS + c];              // 255 mean_c: normalises to zero
+                    vv = l1_channel(vin.v[r], c);
+                    if (r == 0 && J.kb == 0 && keep0 == 0.f) vv = splat4(padv);
+                } else {
+                    vv = (r == 0 && J.kb == 0) ? vin.v[r][c] * splat4(keep0) : vin.v[r][c];      // only the band at the top of a crop has a padding row
+                }
                 const float left = lane_left(vv.w);                 // a wave starts at a row start: lane 0 has qp = 0
-                const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
+                const float t0[3] = {qp > 0 ? left : padv, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             dst[J.HALF + 1 + qp] = f4{a1[0], a1[1], a1[2], a1[3]};
             dst[J.npix1 + J.HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
         };
-        f4 va[3][3], vb[3][3];
+        L1In<U8> va, vb;
         fetch(band(g_lo), va);
         __syncthreads();                 // constants in LDS (the other roles' first reads) -- every role executes this barrier
 #pragma unroll 1

@@ -40,7 +40,9 @@ __device__ __forceinline__ void lin_coeff(int d, int src, double scale, int& s0,
 // 64 / 128 / 256), i.e. whole 256-byte row segments per quarter-wave instead of 4-byte stores.
 // BYTES = true: the same kernel with every 8-byte window assembled from eight single-byte loads -- the form that needs nothing of the
 // device's unaligned-access mode; vt_create's self test (vittrack.hip: crop_selftest) selects it when the fast form's result differs.
-template <bool BYTES = false>
+// U8OUT (round 6): `out` is the uint8 (B, T, T, 3) patch itself -- sample_target's return value, before Preprocessor.process -- which
+// the stems' uint8 forms consume (vt_stem.h: L1In); no normalisation table, a thread's 12 values leave as one 12-byte store.
+template <bool BYTES = false, bool U8OUT = false>
 __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restrict__ frames, int H, int W,
                                                    const double* __restrict__ states, double factor, int T,
                                                    float m0, float m1, float m2, float s0, float s1, float s2,
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
     // workgroup with the reference's arithmetic (three separately rounded fp32 ops, below) into an LDS table -- per output value
     // one LDS read instead of a convert, a multiply, a subtract and an IEEE division sequence (~14 VALU instructions of the ~74 a
     // value cost).
-    __shared__ float norm_lut[3 * 256];
-    {
+    __shared__ float norm_lut[U8OUT ? 1 : 3 * 256];
+    if constexpr (!U8OUT) {
         const float meanv[3] = {m0, m1, m2}, stdq[3] = {s0, s1, s2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
             asm volatile("" : "+v"(centred));
             norm_lut[c * 256 + threadIdx.x] = centred / stdq[c];
         }
+        __syncthreads();
     }
-    __syncthreads();
+    unsigned char* const out8 = reinterpret_cast<unsigned char*>(out) + (size_t)b * T * T * 3;      // U8OUT: this frame's patch
     const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
     const int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
     const int T4 = (T + 3) >> 2;                      // pixel groups per row
@@ -80,7 +83,10 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
         if (idx < T * T4) {
             const int oy = idx / T4, ox0 = (idx - oy * T4) * 4;
             for (int c = 0; c < 3; ++c)
-                for (int k = 0; k < 4 && ox0 + k < T; ++k) out[(((size_t)b * 3 + c) * T + oy) * T + ox0 + k] = __builtin_nanf("");
+                for (int k = 0; k < 4 && ox0 + k < T; ++k) {
+                    if constexpr (U8OUT) out8[((size_t)oy * T + ox0 + k) * 3 + c] = 0;      // bytes cannot carry the poison: the NaN resize factor does
+                    else out[(((size_t)b * 3 + c) * T + oy) * T + ox0 + k] = __builtin_nanf("");
+                }
         }
         return;
     }
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
         return (((unsigned long long)v.y << 32) | v.x) >> (8u * over);
     };
     float res[3][4];
+    unsigned pk[3] = {0u, 0u, 0u};      // U8OUT: the 12 bytes of this thread's four pixels, HWC
     unsigned long long q0[4], q1[4];
     int ax0a[4], ax1a[4], sh1[4];
     bool vc0a[4], vc1a[4];
@@ -155,8 +162,19 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
             const int r1 = __mul24(p10, ax0) + __mul24(p11, ax1);
             int v = ((__mul24(by0, r0 >> 4) >> 16) + (__mul24(by1, r1 >> 4) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            res[c][k] = norm_lut[c * 256 + v];
+            if constexpr (U8OUT) pk[(3 * k + c) >> 2] |= (unsigned)v << (8 * ((3 * k + c) & 3));
+            else res[c][k] = norm_lut[c * 256 + v];
         }
+    }
+    if constexpr (U8OUT) {
+        unsigned char* o = out8 + ((size_t)oy * T + ox0) * 3;
+        if ((T & 3) == 0) {
+            typedef unsigned u3a __attribute__((ext_vector_type(3), aligned(4)));
+            *reinterpret_cast<u3a*>(o) = u3a{pk[0], pk[1], pk[2]};
+        } else {
+            for (int i = 0; i < 12 && ox0 + i / 3 < T; ++i) o[i] = (unsigned char)(pk[i >> 2] >> (8 * (i & 3)));
+        }
+        return;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -187,20 +205,25 @@ __global__ __launch_bounds__(256) void crop_kernel(const unsigned char* __restri
 //   - a load that could cross the end of the buffer (the last rows of the last frame) shifts its window as crop_kernel does, on a
 //     slow path a whole wave takes or skips
 constexpr int CROP_FAST_MAX_T = 512;
+#ifndef VT_CROPF_DBG
+#define VT_CROPF_DBG 0      // timing builds only (wrong results): 1 = no frame loads, 2 = no stores, 4 = every workgroup reads frame 0, 8 = no arithmetic
+#endif
 __device__ __forceinline__ unsigned mulhi24(unsigned a, unsigned b) {      // (a b) >> 32 for a, b < 2^24
     unsigned r;
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-template <int G>
+template <int G, bool U8OUT = false>
 __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __restrict__ frames, int H, int W,
                                                         const double* __restrict__ states, double factor, int T,
                                                         float m0, float m1, float m2, float s0, float s1, float s2,
                                                         float* __restrict__ out, double* __restrict__ resize_factor) {
     const int b = blockIdx.y, tid = threadIdx.x;
-    __shared__ float norm_lut[3 * 256];
+    __shared__ float norm_lut[U8OUT ? 1 : 3 * 256];
     __shared__ __attribute__((aligned(16))) unsigned xtab[CROP_FAST_MAX_T * 4];      // per output column: window byte offset, weights, right column's shift, -
-    {
+    unsigned char* const out8 = reinterpret_cast<unsigned char*>(out) + (size_t)b * T * T * 3;      // U8OUT: this frame's (T, T, 3) patch
+    typedef unsigned u3a __attribute__((ext_vector_type(3), aligned(4)));
+    if constexpr (!U8OUT) {
         const float meanv[3] = {m0, m1, m2}, stdq[3] = {s0, s1, s2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {       // Preprocessor.process on the 256 possible values: see crop_kernel
@@ -221,7 +244,9 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
             const int idx = item0 + g * 256 + tid;
             if (idx < nitems) {
                 const int oy = idx / T4, ox0 = (idx - oy * T4) * 4;
-                for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + ox0, splat4(__builtin_nanf("")));
+                if constexpr (U8OUT) *reinterpret_cast<u3a*>(out8 + ((size_t)oy * T + ox0) * 3) = u3a{0u, 0u, 0u};      // the NaN resize factor carries the poison
+                else
+                    for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + ox0, splat4(__builtin_nanf("")));
             }
         }
         return;
@@ -246,7 +271,7 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
     __syncthreads();
     const size_t frame_bytes = (size_t)H * W * 3, rest = (size_t)(gridDim.y - b) * frame_bytes;
     const unsigned nrec = rest > 0xfffffff0ull ? 0xfffffff0u : (unsigned)rest;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames + (size_t)b * frame_bytes), 0, (int)nrec, 0x00020000);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(frames + ((VT_CROPF_DBG & 4) ? 0 : (size_t)b * frame_bytes)), 0, (int)nrec, 0x00020000);
     typedef unsigned u2v __attribute__((ext_vector_type(2)));
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     struct Item {
@@ -276,6 +301,10 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
             const u4v e = *reinterpret_cast<const u4v*>(xtab + 4 * (it.ox0 + k));
             it.wp[k] = e.y; it.sh[k] = e.z;
             const unsigned o0 = rowo0 + e.x, o1 = rowo1 + e.x;
+            if (VT_CROPF_DBG & 1) {
+                it.q0[k] = ((unsigned long long)o0 << 32) | o1;
+                it.q1[k] = ((unsigned long long)o1 << 32) | o0;
+            } else
             if (slow) {
                 const unsigned ov0 = o0 + 8u > nrec ? o0 + 8u - nrec : 0u, ov1 = o1 + 8u > nrec ? o1 + 8u - nrec : 0u;
                 const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o0 - ov0), 0, 0);
@@ -292,12 +321,14 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
     };
     auto finish = [&](const Item& it) {
         float res[3][4];
+        unsigned pk[3] = {0u, 0u, 0u};      // U8OUT: the 12 bytes of the item's four pixels, HWC
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned l0 = (unsigned)it.q0[k], l1 = (unsigned)it.q1[k];
             const unsigned r0w = __builtin_amdgcn_alignbit((unsigned)(it.q0[k] >> 32), l0, it.sh[k]);       // the window >> 0 or 24 bits
             const unsigned r1w = __builtin_amdgcn_alignbit((unsigned)(it.q1[k] >> 32), l1, it.sh[k]);
             const us2 wv = __builtin_bit_cast(us2, it.wp[k]);
+            if ((VT_CROPF_DBG & 8) && U8OUT) { pk[k % 3] ^= l0 ^ l1 ^ r0w ^ r1w ^ it.wp[k]; continue; }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 // bytes of the result: [left pixel's channel c, 0, right pixel's channel c, 0]
@@ -307,11 +338,20 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
                 // (b (r >> 4)) >> 16 = ((b << 12) (r with its low 4 bits cleared)) >> 32: one 24-bit high multiply (both factors < 2^24)
                 const unsigned t0 = mulhi24(it.byw0, r0 & ~15u), t1 = mulhi24(it.byw1, r1 & ~15u);
                 // v = (t0 + t1 + 2) >> 2, clamped at 255; its table entry is at byte 4 v
+                if constexpr (U8OUT) {
+                    unsigned v = (t0 + t1 + 2u) >> 2;
+                    v = v > 255u ? 255u : v;
+                    pk[(3 * k + c) >> 2] |= v << (8 * ((3 * k + c) & 3));
+                } else {
                 unsigned v4 = (t0 + t1 + 2u) & ~3u;
                 v4 = v4 > 1020u ? 1020u : v4;
                 res[c][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(norm_lut) + c * 1024 + v4);
+                }
             }
         }
+        if constexpr (U8OUT) {
+            if ((VT_CROPF_DBG & 2) ? (pk[0] == 0x12345678u && pk[1] == 0x9abcdef0u) : it.live) *reinterpret_cast<u3a*>(out8 + ((size_t)it.oy * T + it.ox0) * 3) = u3a{pk[0], pk[1], pk[2]};
+        } else
         if (it.live) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + it.oy) * T + it.ox0, f4{res[c][0], res[c][1], res[c][2], res[c][3]});

@@ -25,6 +25,7 @@ SYMBOLS = [
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
     "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record", "vt_track_step", "vt_set_form_batch",
+    "vt_crop_u8", "vt_set_normalization", "vt_forward_u8", "vt_stem_u8", "vt_patch_u8_supported", "vt_crop_form",
 ]
 
 
@@ -95,6 +96,12 @@ def lib(precision: str = "f32"):
     L.vt_set_template.argtypes = [vp, vp, i32, vp]
     L.vt_set_form_batch.argtypes = [vp, i32]
     L.vt_track_step.argtypes = [vp, vp, i32, i32, vp, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float), i32, vp, vp, vp, vp, i32, vp]
+    L.vt_crop_u8.argtypes = [vp, vp, i32, i32, vp, C.c_double, i32, i32, vp, vp, vp]
+    L.vt_set_normalization.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vt_forward_u8.argtypes = [vp, vp, vp, i32, vp, C.POINTER(VtOutputs)]
+    L.vt_stem_u8.argtypes = [vp, vp, i32, vp, vp]
+    L.vt_patch_u8_supported.argtypes = [vp, i32]
+    L.vt_crop_form.argtypes = []
     if precision == "f32":
         _lib = L
     else:
@@ -122,6 +129,12 @@ def _stream(stream):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
     return C.c_void_p(s.cuda_stream)
+
+
+def crop_form() -> int:
+    """Which crop kernel form the current device runs: 1 = 8-byte unaligned windows (crop_fast_kernel / crop_kernel<false>), 2 = the
+    byte-load fallback the device self test selects on any mismatch."""
+    return int(lib().vt_crop_form())
 
 
 def probe_clock(iters=20000, waves_per_simd=1):
@@ -395,6 +408,70 @@ class Model:
                              out_size, m3, s3, B, _stream(stream), _ptr(out), C.c_void_p(resize_factor.data_ptr())),
                "vt_crop", self._L)
         return out, resize_factor
+
+    # ---- the uint8 patch path (round 6): sample_target's output goes to the stem as it is
+    def crop_u8(self, frames, states, factor, out_size, out=None, resize_factor=None, stream=None):
+        """sample_target alone: frames (B,H,W,3) uint8 (GPU or pinned), states (B,4) float64 cuda -> (patch (B,T,T,3) uint8 --
+        the array the reference's sample_target returns --, resize_factor (B) fp64)."""
+        import torch
+        if not ((frames.is_cuda or frames.is_pinned()) and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4
+                and frames.shape[3] == 3):
+            raise VtError("frames must be a contiguous (B,H,W,3) uint8 tensor on the GPU (or in pinned host memory)")
+        if not (states.is_cuda and states.dtype == torch.float64 and states.is_contiguous()):
+            raise VtError("states must be a contiguous (B,4) float64 tensor on the GPU")
+        B, H, W, _ = frames.shape
+        if tuple(states.shape) != (B, 4):
+            raise VtError(f"states must be ({B},4) for {B} frames, got {tuple(states.shape)}")
+        if out is None:
+            out = torch.empty(B, out_size, out_size, 3, dtype=torch.uint8, device=states.device)
+        elif tuple(out.shape) != (B, out_size, out_size, 3) or out.dtype != torch.uint8 or not out.is_cuda or not out.is_contiguous():
+            raise VtError(f"patch output must be a contiguous ({B},{out_size},{out_size},3) uint8 tensor on the GPU")
+        if resize_factor is None:
+            resize_factor = torch.empty(B, dtype=torch.float64, device=states.device)
+        elif tuple(resize_factor.shape) != (B,) or resize_factor.dtype != torch.float64 or not resize_factor.is_cuda:
+            raise VtError(f"resize_factor must be a ({B},) float64 tensor on the GPU")
+        _check(self._L.vt_crop_u8(self._h, C.c_void_p(frames.data_ptr()), H, W, C.c_void_p(states.data_ptr()), float(factor), out_size, B,
+                                _stream(stream), C.c_void_p(out.data_ptr()), C.c_void_p(resize_factor.data_ptr())), "vt_crop_u8", self._L)
+        return out, resize_factor
+
+    def set_normalization(self, mean, std):
+        """Preprocessor's mean / std for the uint8 entry points (folded into the stem's first layer; default: ImageNet)."""
+        m3 = (C.c_float * 3)(*[float(v) for v in mean])
+        s3 = (C.c_float * 3)(*[float(v) for v in std])
+        _check(self._L.vt_set_normalization(self._h, m3, s3), "vt_set_normalization", self._L)
+
+    def patch_u8_supported(self, B: int) -> bool:
+        return bool(self._L.vt_patch_u8_supported(self._h, int(B)))
+
+    def _check_patch(self, xp):
+        import torch
+        B, tx = xp.shape[0], self.search_size
+        if tuple(xp.shape) != (B, tx, tx, 3) or xp.dtype != torch.uint8 or not xp.is_cuda or not xp.is_contiguous():
+            raise VtError(f"expected a contiguous uint8 patch (B,{tx},{tx},3) on the GPU, got {tuple(xp.shape)} {xp.dtype}")
+        self._check_batch(B)
+        return B
+
+    def forward_u8(self, z, x_patch, out: Outputs | None = None, stream=None) -> Outputs:
+        """Preprocessor.process + forward on the uint8 search patch of crop_u8; z: fp32 template crop or None (cached template)."""
+        B = self._check_patch(x_patch)
+        if z is None:
+            if getattr(self, "_tmpl_B", 0) < B:
+                raise VtError(f"forward_u8 with z=None needs set_template() for at least {B} frames first")
+        elif tuple(z.shape) != (B, 3, self.template_size, self.template_size):
+            raise VtError(f"expected z ({B},3,{self.template_size},{self.template_size}), got {tuple(z.shape)}")
+        out = out or Outputs(B, self.feat_sz, x_patch.device)
+        self._check_out(out, B)
+        st = out.struct()
+        _check(self._L.vt_forward_u8(self._h, _ptr(z), C.c_void_p(x_patch.data_ptr()), B, _stream(stream), C.byref(st)), "vt_forward_u8", self._L)
+        return out
+
+    def stem_u8(self, x_patch, tokens, stream=None):
+        """Search rows of the token matrix from a uint8 patch (rows [len_z, L) of `tokens` (B,L,C) are written)."""
+        B = self._check_patch(x_patch)
+        if tuple(tokens.shape) != (B, self.len_z + self.len_x, self.channels):
+            raise VtError(f"tokens must be ({B},{self.len_z + self.len_x},{self.channels}), got {tuple(tokens.shape)}")
+        _check(self._L.vt_stem_u8(self._h, C.c_void_p(x_patch.data_ptr()), B, _stream(stream), _ptr(tokens)), "vt_stem_u8", self._L)
+        return tokens
 
     def update_state(self, hann_boxes, resize_factor, states, search_size, H, W, margin=10, stream=None):
         B = states.shape[0]

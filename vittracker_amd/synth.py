@@ -93,6 +93,35 @@ def synth_inputs(seed: int, B: int, template_size: int, search_size: int):
     return z, x
 
 
+def synth_patches(seed: int, B: int, size: int) -> np.ndarray:
+    """Seeded uint8 (B, size, size, 3) patches, the shape sample_target returns (lib/train/data/processing_utils.py:68-79): even
+    frames are uniform noise over all 256 values (every byte value, the extremes included), odd ones a smooth field (a coarse
+    random grid repeated 8 x 8) plus small noise and a black band at one border, as a crop that reaches over the frame has."""
+    rs = np.random.RandomState(2_000_003 + seed)
+    out = np.empty((B, size, size, 3), np.uint8)
+    for b in range(B):
+        if b % 2 == 0:
+            out[b] = rs.randint(0, 256, (size, size, 3))
+        else:
+            coarse = rs.randint(0, 256, (size // 8, size // 8, 3)).astype(np.int64)
+            img = np.repeat(np.repeat(coarse, 8, axis=0), 8, axis=1) + rs.randint(-6, 7, (size, size, 3))
+            img = np.clip(img, 0, 255)
+            img[:, : size // 5] = 0
+            out[b] = img
+    return out
+
+
+def normalise_patches(patches: np.ndarray, reciprocal: bool = True) -> np.ndarray:
+    """Preprocessor.process (lib/test/tracker/data_utils.py:11-17) in float32: HWC uint8 -> NCHW ((u / 255) - mean) / std.  torch on
+    a GPU evaluates `tensor / 255.0` as a multiplication by float32(1 / 255) (reciprocal=True: what the reference's tracker runs and
+    what vt_crop reproduces bit for bit); on the CPU it divides (reciprocal=False)."""
+    mean = np.array([0.485, 0.456, 0.406], np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], np.float32).reshape(1, 3, 1, 1)
+    t = patches.astype(np.float32).transpose(0, 3, 1, 2)
+    t = t * (np.float32(1.0) / np.float32(255.0)) if reciprocal else t / np.float32(255.0)
+    return np.ascontiguousarray(((t - mean) / std).astype(np.float32))
+
+
 def state_checksum(sd: dict) -> str:
     h = hashlib.sha256()
     for k in sorted(sd):
