@@ -23,6 +23,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
+    ap.add_argument("--hold-boxes", action="store_true",
+                    help="reset every sequence's box to its initial one before each step (an 8 KB device copy per step inside the timed loops): on "
+                         "noise frames with random weights the boxes drift to the clip limits within a few frames -- 10 px wide at G128, the whole "
+                         "frame at G256 -- and the crop then reads a 40 px or a 2200 px window; held boxes keep the 120-360 px windows of a tracker "
+                         "that follows a target")
     ap.add_argument("--one-stream", action="store_true", help="stop before the two-shard phase (profiling: per-kernel times of ONE step in flight)")
     a = ap.parse_args()
     if a.geom:
@@ -40,6 +45,8 @@ def main():
     boxes = np.stack([rs.uniform(50, W - 150, B), rs.uniform(50, H - 150, B), rs.uniform(30, 90, B), rs.uniform(30, 90, B)], 1)
     bt = BatchedVitTracker(p, B)
     bt.initialize(frames[0], boxes)
+    if a.hold_boxes:
+        bt.hold_states(True)
     for f in range(3):
         bt.track(frames[f & 1], sync=False)
     torch.cuda.synchronize()
@@ -62,6 +69,10 @@ def main():
     dt = time.time() - t0
     print(f"frames already on the device: {B * a.frames / dt:.0f} frames/s, {dt / a.frames * 1e3:.3f} ms per step")
     print("last boxes[0]:", out["target_bbox"][0].tolist())
+    bb = out["target_bbox"].cpu().numpy()
+    side = np.sqrt(bb[:, 2] * bb[:, 3])
+    print(f"box sides sqrt(w h) after {bt.frame_id} frames: min {side.min():.1f} median {np.median(side):.1f} max {side.max():.1f} px "
+          f"(the crop reads a square of search_factor x that side)")
     for n in (2, 4):      # n frames per graph launch (crop -> forward -> state update, n times, one graph)
         chunk = dev[[i & 1 for i in range(n)]].contiguous()
         for _ in range(3):       # the first replays of a fresh graph include its upload

@@ -911,6 +911,30 @@ void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const do
     static const int fast = [] { const char* v = std::getenv("VT_CROP_FAST"); return v && *v ? std::atoi(v) : 1; }();     // groups per workgroup (1, 2, 4); 0: crop_kernel
     static const float none3[3] = {0.f, 1.f, 1.f};
     if (u8out) mean3 = std3 = none3;
+    // the tracker's sizes: crop_band_kernel (a workgroup owns a band of VT_CROP_BAND x 256 items; 0: crop_fast_kernel as in round 5)
+    static const int band = [] { const char* v = std::getenv("VT_CROP_BAND"); return v && *v ? std::atoi(v) : 4; }();
+    if (!bytes && fast > 0 && band > 0 && (T == 64 || T == 128 || T == 256)) {
+        auto go = [&](auto kernel, int ipt) {
+            hipLaunchKernelGGL(kernel, dim3(T * (T / 4) / (256 * ipt), B), dim3(256), 0, st, frames, H, W, states, factor, mean3[0], mean3[1], mean3[2],
+                               std3[0], std3[1], std3[2], crops, rf);
+        };
+        static const int aligned = [] { const char* v = std::getenv("VT_CROP_ALIGNED"); return v && *v ? std::atoi(v) : 1; }();     // 0: byte-aligned 8-byte windows
+        const int ipt = band >= 4 ? 4 : 2;
+        auto pick = [&](auto u8c, auto lgc) {
+            constexpr bool U = decltype(u8c)::value;
+            constexpr int LG = decltype(lgc)::value;
+            if (aligned) ipt == 4 ? go(&vtt::crop_band_kernel<U, LG, 4, true>, 4) : go(&vtt::crop_band_kernel<U, LG, 2, true>, 2);
+            else ipt == 4 ? go(&vtt::crop_band_kernel<U, LG, 4, false>, 4) : go(&vtt::crop_band_kernel<U, LG, 2, false>, 2);
+        };
+        auto by_size = [&](auto u8c) {
+            if (T == 64) pick(u8c, std::integral_constant<int, 4>{});
+            else if (T == 128) pick(u8c, std::integral_constant<int, 5>{});
+            else pick(u8c, std::integral_constant<int, 6>{});
+        };
+        if (u8out) by_size(std::true_type{});
+        else by_size(std::false_type{});
+        return;
+    }
     if (!bytes && fast > 0 && (T & 3) == 0 && T <= vtt::CROP_FAST_MAX_T) {
         const int ngroups = (T * (T / 4) + 255) / 256;
         if (u8out) {

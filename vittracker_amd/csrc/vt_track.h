@@ -213,6 +213,16 @@ __device__ __forceinline__ unsigned mulhi24(unsigned a, unsigned b) {      // (a
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// dst's byte N = (v >> 2) & 0xff, its other bytes kept: the vertical pass's final shift written straight into the packed patch bytes
+// (SDWA destination select; `two` = a register holding 2)
+__device__ __forceinline__ void put_byte_shr2(unsigned& dst, unsigned v, unsigned two, int n) {      // n: a constant once the callers' loops are unrolled
+    switch (n) {
+        case 0: asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(two), "v"(v)); break;
+        case 1: asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(two), "v"(v)); break;
+        case 2: asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(two), "v"(v)); break;
+        default: asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(dst) : "v"(two), "v"(v)); break;
+    }
+}
 template <int G, bool U8OUT = false>
 __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __restrict__ frames, int H, int W,
                                                         const double* __restrict__ states, double factor, int T,
@@ -363,6 +373,221 @@ __global__ __launch_bounds__(256) void crop_fast_kernel(const unsigned char* __r
     for (int g = 0; g < G; ++g) {
         if (g + 1 < G) fetch(g + 1, buf[(g + 1) & 1]);
         finish(buf[g & 1]);
+    }
+}
+
+// crop_band_kernel (round 6) -- the crop at the tracker's sizes (T = 64 / 128 / 256: T / 4 = 2^LGT4 column groups), same arithmetic and
+// results bit for bit as crop_fast_kernel / crop_kernel.  Measured on timing builds of crop_fast_kernel (tools/crop_ab.py, T = 128, 256
+// frames, us per launch alone): everything 13.8 * no frame loads 11.6 * no loads and no stores 9.3 * no arithmetic 12.9; T = 256: 39.2 for
+// 4 x the items -- the kernel is bound by the vector instructions it issues (~500 per item of 12 values, of which the fp64 box geometry,
+// the column entry, the row coefficients and the index arithmetic every thread repeats are ~210), not by its traffic.  Here a workgroup
+// owns a BAND of IPT x 256 items and a thread IPT items of ONE column group:
+//   - geometry, the column table and the band's row table (row byte offsets + vertical weights, one entry per output row) are computed
+//     once per IPT x 256 items; a thread reads its four column entries into registers once and one row entry per item
+//   - the IPT x 8 window loads of a thread are all in flight before the first item's arithmetic (what a thread per item had in flight
+//     as IPT threads), instead of crop_fast_kernel<G>'s two-deep software pipeline, which halved the loads in flight and lost (NOTES R5-8)
+//   - only the LAST frame of the batch can read past the buffer's end: the shifted-window slow path is a workgroup-uniform branch
+//   - ALIGNED: stamps (tools/crop_stamps.py, -DVT_CROPF_DBG=16) put 12.3 k of a band's 16.6 k cycles into ISSUING its 32 window loads per
+//     thread: a byte-aligned 8-byte gather costs the CU's address path ~34 cycles per wave-load against 18 for any dword-aligned load of
+//     up to 16 bytes (tools/src/probe_gather.hip), and 512 of them per CU and round is what the kernel waits for.  So a window is fetched
+//     as the 12 ALIGNED bytes that contain it (the two pixels' 6 bytes start at byte 0..3 of them) and shifted into place with two
+//     v_alignbit; the batch's last frame keeps the byte-aligned form (its shifted-back windows).
+template <bool U8OUT, int LGT4, int IPT, bool ALIGNED>
+__global__ __launch_bounds__(256) void crop_band_kernel(const unsigned char* __restrict__ frames, int H, int W,
+                                                        const double* __restrict__ states, double factor,
+                                                        float m0, float m1, float m2, float s0, float s1, float s2,
+                                                        float* __restrict__ out, double* __restrict__ resize_factor) {
+    constexpr int T4 = 1 << LGT4, T = 4 * T4, RPG = 256 >> LGT4, NROWS = IPT * RPG;      // rows per group of 256 items, rows per band
+    static_assert(T <= 256 && (T * T4) % (IPT * 256) == 0, "a band is whole rows and the frame whole bands");
+    const int b = blockIdx.y, tid = threadIdx.x;
+    // VT_CROPF_DBG & 16 (timing build, uint8 form): s_memtime at the phase boundaries of every workgroup, written over the first 48 bytes of its band
+    unsigned long long stamp_[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) {
+        if constexpr ((VT_CROPF_DBG & 16) != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_[i])::"memory");
+    };
+    stamp(0);
+    __shared__ float norm_lut[U8OUT ? 1 : 3 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned xtab[T * 4];          // per output column: window byte offset, packed weights, right column's shift, -
+    __shared__ __attribute__((aligned(16))) unsigned ytab[NROWS * 4];      // per output row of the band: byte offsets of its two source rows, their weights << 12
+    unsigned char* const out8 = reinterpret_cast<unsigned char*>(out) + (size_t)b * T * T * 3;
+    typedef unsigned u3a __attribute__((ext_vector_type(3), aligned(4)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    if constexpr (!U8OUT) {
+        const float meanv[3] = {m0, m1, m2}, stdq[3] = {s0, s1, s2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {       // Preprocessor.process on the 256 possible values: see crop_kernel
+            float scaled = (float)tid * (1.0f / 255.0f);
+            asm volatile("" : "+v"(scaled));
+            float centred = scaled - meanv[c];
+            asm volatile("" : "+v"(centred));
+            norm_lut[c * 256 + tid] = centred / stdq[c];
+        }
+    }
+    const double bx = states[4 * b + 0], by = states[4 * b + 1], bw = states[4 * b + 2], bh = states[4 * b + 3];
+    const int crop_sz = (int)ceil(sqrt(bw * bh) * factor);
+    const int row0 = blockIdx.x * NROWS;                 // first output row of this band
+    const int cg = tid & (T4 - 1), rl = tid >> LGT4;     // this thread's column group and its row inside a group of 256 items
+    if (!(crop_sz >= 1)) {                  // 'Too small bounding box.': NaN poison, as crop_kernel
+        if (blockIdx.x == 0 && tid == 0) resize_factor[b] = __builtin_nan("");
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int oy = row0 + j * RPG + rl;
+            if constexpr (U8OUT) *reinterpret_cast<u3a*>(out8 + ((size_t)oy * T + 4 * cg) * 3) = u3a{0u, 0u, 0u};
+            else
+                for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + 4 * cg, splat4(__builtin_nanf("")));
+        }
+        return;
+    }
+    const int x1 = (int)rint(bx + 0.5 * bw - crop_sz * 0.5);
+    const int y1 = (int)rint(by + 0.5 * bh - crop_sz * 0.5);
+    const int x2 = x1 + crop_sz, y2 = y1 + crop_sz;
+    const int vx0 = x1 < 0 ? 0 : x1, vx1 = x2 - (x2 - W + 1 > 0 ? x2 - W + 1 : 0);
+    const int vy0 = y1 < 0 ? 0 : y1, vy1 = y2 - (y2 - H + 1 > 0 ? y2 - H + 1 : 0);
+    if (blockIdx.x == 0 && tid == 0) resize_factor[b] = (double)T / (double)crop_sz;
+    const double scale = (double)crop_sz / (double)T;
+    if ((VT_CROPF_DBG & 16) != 0) { asm volatile("" ::"v"(x1), "v"(y1), "v"(scale)); stamp(1); }
+    if (tid < T) {                          // column entries (as crop_fast_kernel)
+        int sx0, sx1, ax0, ax1;
+        lin_coeff(tid, crop_sz, scale, sx0, sx1, ax0, ax1);
+        const int xx0 = x1 + sx0, xx1 = x1 + sx1;
+        const bool vc0 = xx0 >= vx0 && xx0 < vx1, vc1 = xx1 >= vx0 && xx1 < vx1;
+        const int xb = vc0 ? xx0 : (vc1 ? xx1 : 0);
+        *reinterpret_cast<u4v*>(xtab + 4 * tid) = u4v{3u * (unsigned)xb, (unsigned)(vc0 ? ax0 : 0) | ((unsigned)(vc1 ? ax1 : 0) << 16),
+                                                       (unsigned)(vc1 ? 24 * (xx1 - xb) : 0), 0u};
+    }
+    if (tid >= 256 - NROWS) {               // row entries of the band, by the LAST threads (the first T are busy with the columns)
+        const int r = tid - (256 - NROWS);
+        int sy0, sy1, by0, by1;
+        lin_coeff(row0 + r, crop_sz, scale, sy0, sy1, by0, by1);
+        const int yy0 = y1 + sy0, yy1 = y1 + sy1;
+        const bool vr0 = yy0 >= vy0 && yy0 < vy1, vr1 = yy1 >= vy0 && yy1 < vy1;
+        *reinterpret_cast<u4v*>(ytab + 4 * r) = u4v{(unsigned)(vr0 ? yy0 : 0) * (unsigned)(W * 3), (unsigned)(vr1 ? yy1 : 0) * (unsigned)(W * 3),
+                                                     vr0 ? (unsigned)by0 << 12 : 0u, vr1 ? (unsigned)by1 << 12 : 0u};      // a padded row weighs nothing
+    }
+    __syncthreads();
+    stamp(2);
+    const size_t frame_bytes = (size_t)H * W * 3, rest = (size_t)(gridDim.y - b) * frame_bytes;
+    const unsigned nrec = rest > 0xfffffff0ull ? 0xfffffff0u : (unsigned)rest;
+    const unsigned char* const fb = frames + (size_t)b * frame_bytes;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(fb), 0, (int)nrec, 0x00020000);
+    // ALIGNED: the same bytes through a descriptor whose base is the frame's address rounded DOWN to a dword; offsets carry the remainder
+    const unsigned mis = (unsigned)(reinterpret_cast<unsigned long long>(fb) & 3ull);
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(fb - mis), 0, (int)(nrec > 0xfffffff0u - 4u ? nrec : nrec + mis), 0x00020000);
+    unsigned xo[4], wp[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u4v e = *reinterpret_cast<const u4v*>(xtab + 4 * (4 * cg + k));
+        xo[k] = e.x + (ALIGNED ? mis : 0u); wp[k] = e.y; sh[k] = e.z;
+    }
+    typedef unsigned u3v __attribute__((ext_vector_type(3)));
+    // a window can cross the end of the buffer only in the batch's last frame (its last rows): there every load takes the byte-aligned,
+    // shifted-back form.  The two forms are two instantiations of one body (AL: aligned 12-byte loads), so neither holds the other's registers.
+    const bool last = b == (int)gridDim.y - 1;
+    unsigned two = 2u;
+    asm volatile("" : "+v"(two));      // put_byte_shr2's shift operand has to live in a vector register
+    const bool col_live = (wp[0] | wp[1] | wp[2] | wp[3]) != 0u;
+    auto body = [&](auto al_c) {
+        constexpr bool AL = decltype(al_c)::value;
+        u2v q0[AL ? 1 : IPT][4], q1[AL ? 1 : IPT][4];
+        u3v ra0[AL ? IPT : 1][4], ra1[AL ? IPT : 1][4];      // AL: the 12 aligned bytes around each window ...
+        unsigned ro0[IPT], ro1[IPT];                          // ... and the item's row offsets: a window's shift is 8 x its offset's low two bits
+        unsigned byw0[IPT], byw1[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const u4v e = *reinterpret_cast<const u4v*>(ytab + 4 * (j * RPG + rl));
+            byw0[j] = e.z; byw1[j] = e.w; ro0[j] = e.x; ro1[j] = e.y;
+            // an item whose two rows or whose four columns all lie in the crop's zero padding (a window reaching over the frame's
+            // border) weighs nothing: its loads are skipped, the products below are 0 x 0
+            const bool live = ((e.z | e.w) != 0u) && col_live;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned o0 = e.x + xo[k], o1 = e.y + xo[k];
+                if (!live) {
+                    if constexpr (AL) { ra0[j][k] = u3v{0u, 0u, 0u}; ra1[j][k] = u3v{0u, 0u, 0u}; }
+                    else { q0[j][k] = u2v{0u, 0u}; q1[j][k] = u2v{0u, 0u}; }
+                } else
+                if constexpr (AL) {
+                    // raw 12 aligned bytes now; the funnel shift where they are used
+                    ra0[j][k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_a, (int)(o0 & ~3u), 0, 0);
+                    ra1[j][k] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_a, (int)(o1 & ~3u), 0, 0);
+                } else {
+                    if (ALIGNED) { o0 -= mis; o1 -= mis; }
+                    if (last) {
+                        const unsigned ov0 = o0 + 8u > nrec ? o0 + 8u - nrec : 0u, ov1 = o1 + 8u > nrec ? o1 + 8u - nrec : 0u;
+                        const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o0 - ov0), 0, 0);
+                        const u2v c = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(o1 - ov1), 0, 0);
+                        const unsigned long long wa = (((unsigned long long)a.y << 32) | a.x) >> (8u * ov0), wc = (((unsigned long long)c.y << 32) | c.x) >> (8u * ov1);
+                        q0[j][k] = u2v{(unsigned)wa, (unsigned)(wa >> 32)};
+                        q1[j][k] = u2v{(unsigned)wc, (unsigned)(wc >> 32)};
+                    } else {
+                        q0[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o0, 0, 0);
+                        q1[j][k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)o1, 0, 0);
+                    }
+                }
+            }
+        }
+        if ((VT_CROPF_DBG & 16) != 0) {
+            stamp(3);                                   // every load issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(4);                                   // every window here
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int oy = row0 + j * RPG + rl;
+            float res[3][4];
+            unsigned pk[3] = {0u, 0u, 0u};      // U8OUT: the 12 bytes of the item's four pixels, HWC
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u2v w0, w1;
+                if constexpr (AL) {      // v_alignbit reads bits [4:0] of its shift: 8 x (offset & 3)
+                    const unsigned b0 = (ro0[j] + xo[k]) << 3, b1 = (ro1[j] + xo[k]) << 3;
+                    w0 = u2v{__builtin_amdgcn_alignbit(ra0[j][k].y, ra0[j][k].x, b0), __builtin_amdgcn_alignbit(ra0[j][k].z, ra0[j][k].y, b0)};
+                    w1 = u2v{__builtin_amdgcn_alignbit(ra1[j][k].y, ra1[j][k].x, b1), __builtin_amdgcn_alignbit(ra1[j][k].z, ra1[j][k].y, b1)};
+                } else {
+                    w0 = q0[j][k]; w1 = q1[j][k];
+                }
+                const unsigned l0 = w0.x, l1 = w1.x;
+                const unsigned r0w = __builtin_amdgcn_alignbit(w0.y, l0, sh[k]);       // the window >> 0 or 24 bits
+                const unsigned r1w = __builtin_amdgcn_alignbit(w1.y, l1, sh[k]);
+                const us2 wv = __builtin_bit_cast(us2, wp[k]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned sel = 0x0c040c00u + 0x00010001u * (unsigned)c;       // [left pixel's channel c, 0, right pixel's channel c, 0]
+                    const unsigned r0 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r0w, l0, sel)), wv, 0u, false);
+                    const unsigned r1 = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(r1w, l1, sel)), wv, 0u, false);
+                    const unsigned t0 = mulhi24(byw0[j], r0 & ~15u), t1 = mulhi24(byw1[j], r1 & ~15u);      // (b (r >> 4)) >> 16, see crop_fast_kernel
+                    // t0 + t1 <= (by0 + by1) * 32640 >> 16 = 1020 (the weights of a pair sum to 2048, r >> 4 <= 255 * 128): the reference's
+                    // saturation can never act, so no clamp here (crop_kernel / crop_fast_kernel keep theirs: same results)
+                    if constexpr (U8OUT) {
+                        put_byte_shr2(pk[(3 * k + c) >> 2], t0 + t1 + 2u, two, (3 * k + c) & 3);
+                    } else {
+                        const unsigned v4 = (t0 + t1 + 2u) & ~3u;
+                        res[c][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(norm_lut) + c * 1024 + v4);
+                    }
+                }
+            }
+            if constexpr (U8OUT) {
+                *reinterpret_cast<u3a*>(out8 + ((size_t)oy * T + 4 * cg) * 3) = u3a{pk[0], pk[1], pk[2]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + 4 * cg, f4{res[c][0], res[c][1], res[c][2], res[c][3]});
+            }
+        }
+    };
+    if (ALIGNED && !last) body(std::integral_constant<bool, ALIGNED>{});
+    else body(std::false_type{});
+    if constexpr ((VT_CROPF_DBG & 16) != 0 && U8OUT) {
+        stamp(5);
+        {   // where this workgroup ran: HW_ID (wave / SIMD / CU / SH / SE ids) and XCC_ID
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+            stamp_[6] = ((unsigned long long)xcc << 32) | hw;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int i = 0; i < 7; ++i) reinterpret_cast<unsigned long long*>(out8 + (size_t)row0 * T * 3)[i] = stamp_[i];
     }
 }
 
