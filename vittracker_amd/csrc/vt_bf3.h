@@ -19,7 +19,46 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // x = h + m + l.  Element r of a result piece = bf16 bits of x[r]'s piece; two elements per dword, low half first.
+//
+// Round 6, measured and NOT the default (VT_SPLIT_DOT2=1 builds it): 14 instead of 22 vector instructions per four values.  A residual is
+// x - trunc_bf16(x): the packed pair [h0 | h1] that the MFMA operand needs anyway is also what v_dot2c_f32_bf16 reads -- D += A.lo B.lo +
+// A.hi B.hi with B = [-1 | 0] (or [0 | -1]) and D = x0 (x1) IS the residual, one instruction instead of v_and + v_sub.  It is exact on
+// the hardware (tools/src/probe_split.hip: 130,560 values over every exponent, denormals included, 0 pieces differ from the v_and /
+// v_sub form) -- but v_dot2c_f32_bf16 issues at about a QUARTER of the plain rate: 111 cycles per split and wave against 89 for the
+// 22-instruction form (same probe, four waves per SIMD).  So the split stays 22 plain instructions (NOTES R6-3).
+#ifndef VT_SPLIT_DOT2
+#define VT_SPLIT_DOT2 0
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// x0 - lo(pair), x1 - hi(pair): the residuals of the two values whose leading pieces are packed in `pair`
+__device__ __forceinline__ void sub_pair(unsigned pair, float x0, float x1, float& r0, float& r1) {
+    const bf16x2 a = __builtin_bit_cast(bf16x2, pair);
+    // the two selectors live in registers the compiler cannot see through: written as literals, hipcc 7.2 encodes 0x0000bf80 as the
+    // INLINE constant -1.0, which the instruction then reads as the fp32 pattern 0xbf800000 = [0 | -1] -- the other element
+    unsigned sel_lo = 0x0000bf80u, sel_hi = 0xbf800000u;
+    asm volatile("" : "+s"(sel_lo), "+s"(sel_hi));
+    r0 = __builtin_amdgcn_fdot2_f32_bf16(a, __builtin_bit_cast(bf16x2, sel_lo), x0, false);      // B = [-1 | 0]
+    r1 = __builtin_amdgcn_fdot2_f32_bf16(a, __builtin_bit_cast(bf16x2, sel_hi), x1, false);      // B = [0 | -1]
+}
 __device__ __forceinline__ void split3(f4 x, u32x2& h, u32x2& m, u32x2& l) {
+#ifdef VT_SPLIT_FAKE      // timing builds only (wrong results): the two packs of h, m = l = h -- what the kernels cost WITHOUT the 16 residual instructions
+    h = u32x2{__builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u), __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u)};
+    m = h; l = h;
+    asm volatile("" : "+v"(m), "+v"(l));
+    return;
+#endif
+#if VT_SPLIT_DOT2
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        float r0, r1, s0, s1;
+        h[p] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        sub_pair(h[p], x0, x1, r0, r1);
+        m[p] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        sub_pair(m[p], r0, r1, s0, s1);
+        l[p] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+#else
     unsigned xb[4], r1b[4], r2b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -32,6 +71,7 @@ __device__ __forceinline__ void split3(f4 x, u32x2& h, u32x2& m, u32x2& l) {
     h = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
     m = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
     l = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
+#endif
 }
 // the fp32 value back from its pieces (exact: h + m has at most 16 significant bits, + l at most 24)
 __device__ __forceinline__ f4 join3(u32x2 h, u32x2 m, u32x2 l) {

@@ -1265,6 +1265,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             u32x2 pl[3];            // pieces of the pair's first tile
             f2 ua, ub, na, nb, pa, pb, ea, eb;      // GELU state between stages (pairs (x, y) and (z, w) of `prev`)
             unsigned xb[4], r1b[4], r2b[4];
+            u32x2 hpk, mpk;      // VT_SPLIT_DOT2: the packed h / m pieces, which the residuals are computed from (vt_bf3.h)
             auto gstage = [&](int e) {
                 const auto fma2 = [](f2 p, f2 n, float c) { return __builtin_elementwise_fma(p, n, f2{c, c}); };
                 if (e == 0) {
@@ -1287,20 +1288,45 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
                 } else if (e == 3) {
                     const f2 ga = __builtin_elementwise_fma(na, ea, ua), gb = __builtin_elementwise_fma(nb, eb, ub);
                     const float gv[4] = {ga.x, ga.y, gb.x, gb.y};
+#if VT_SPLIT_DOT2
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        float r0, r1;
+                        hpk[p2] = __builtin_amdgcn_perm(__float_as_uint(gv[2 * p2 + 1]), __float_as_uint(gv[2 * p2]), 0x07060302u);
+                        vt3::sub_pair(hpk[p2], gv[2 * p2], gv[2 * p2 + 1], r0, r1);
+                        r1b[2 * p2] = __float_as_uint(r0); r1b[2 * p2 + 1] = __float_as_uint(r1);
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         xb[k] = __float_as_uint(gv[k]);
                         r1b[k] = __float_as_uint(gv[k] - __uint_as_float(xb[k] & 0xffff0000u));
                     }
+#endif
                 } else if (e == 4) {
+#if VT_SPLIT_DOT2
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        float r0, r1;
+                        mpk[p2] = __builtin_amdgcn_perm(r1b[2 * p2 + 1], r1b[2 * p2], 0x07060302u);
+                        vt3::sub_pair(mpk[p2], __uint_as_float(r1b[2 * p2]), __uint_as_float(r1b[2 * p2 + 1]), r0, r1);
+                        r2b[2 * p2] = __float_as_uint(r0); r2b[2 * p2 + 1] = __float_as_uint(r1);
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k) r2b[k] = __float_as_uint(__uint_as_float(r1b[k]) - __uint_as_float(r1b[k] & 0xffff0000u));
+#endif
                 }
             };
             auto gfinish = [&](int t) {      // the six packs; t = the tile the pieces belong to
                 u32x2 pc3[3];
+#if VT_SPLIT_DOT2
+                pc3[0] = hpk;
+                pc3[1] = mpk;
+#else
                 pc3[0] = u32x2{__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
                 pc3[1] = u32x2{__builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u), __builtin_amdgcn_perm(r1b[3], r1b[2], 0x07060302u)};
+#endif
                 pc3[2] = u32x2{__builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u), __builtin_amdgcn_perm(r2b[3], r2b[2], 0x07060302u)};
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) asm volatile("" : "+v"(pc3[pc]));

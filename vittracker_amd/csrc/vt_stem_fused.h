@@ -349,8 +349,20 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
     else if (t >= 332 && t < 344) csrc = b4 + 4 * (t - 332);
     const f4 cst = ld4(csrc);
     __builtin_amdgcn_sched_barrier(0);
+    // Round 6: wave w of a group issues its first band's loads w x VT_SF_STAGGER x 64 cycles late.  All 256 workgroups start together and ask
+    // for 25 MB at once; issued in the same cycle, every wave's nine loads come back with the LAST of them (the ~6.5 k-cycle prologue).
+    // Staggered, the memory system serves the waves in order and wave 0 computes while wave 7's rows are still on their way.  Measured
+    // (tools/ab_stages.py, two box sessions, us per launch): 0: 21.1-21.2 * 4: 21.1 * 6: 20.45-20.54 * 8: 20.7 * 10: 21.5 * 16: 24.0.
+#ifndef VT_SF_STAGGER
+#define VT_SF_STAGGER 6
+#endif
+    auto stagger = [&](int slots) {
+        if constexpr (VT_SF_STAGGER > 0)
+            for (int i = 0; i < slots * VT_SF_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);
+    };
     if (grp == 0) {      // every thread that holds a constant is in group A (t < 344): fetch and LDS write in one straight line,
                          // so the wait in front of the write is a counted one (the nine crop loads stay in flight)
+        stagger(gw);
         if (do_z) fetch(bz, v);
         if (has_c) cw2[t] = cst;
     }
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(1024) void stem_fused_kernel(
             m2[M2Z_OFF + pl * G::NPIX2Z + (k < 17 ? k : (k - 17) * 17 + 8)] = splat4(0.f);
         }
     }
-    if (grp == 1 && do_x) fetch(bx0, v);     // behind group A's requests (delaying it further changed nothing: measured)
+    if (grp == 1 && do_x) { stagger(do_z ? 8 + gw : gw); fetch(bx0, v); }     // behind group A's requests (delaying it further changed nothing: measured)
     stamp();
     // No barrier here: nothing written above is read before the first interval's barrier (layer 1 reads no LDS,
     // and its ring writes do not overlap the entries cleared above).
