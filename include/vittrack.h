@@ -217,7 +217,7 @@ void vt_graph_destroy(vt_graph* g);
  * ORDER: the value applies to LATER calls only.  Set it before vt_set_template and before any vt_graph_capture[_steps]: the template
  * cache holds the operands of the form it was written under (vt_forward(z = NULL) / vt_track_step return VT_ERR_STATE until
  * vt_set_template has run again under the new value), and captured graphs keep the forms of their capture (changing the value on a
- * model that has captured graphs returns VT_ERR_STATE). */
+ * model that has LIVE captured graphs returns VT_ERR_STATE; once every graph of the model has been destroyed the value is free again). */
 int vt_set_form_batch(vt_model* m, int32_t n);
 
 /* Geometry / workspace queries (host side of build_box_head: feat_sz etc.). */

@@ -247,7 +247,15 @@ def test_form_batch_makes_a_small_batch_run_the_large_batch_forms(geom):
     small.set_form_batch(0)                          # unchanged value: accepted
     with pytest.raises(native.VtError, match="vt_graph_capture"):
         small.set_form_batch(256)                    # the captured graph keeps the forms of its capture
-    del graph
+    small._graphs.discard(graph)
+    del graph                                        # ... and only while it lives: the last graph destroyed, the value is free again
+    small.set_form_batch(256)
+    # a graph that outlives its model is still destroyed safely (vt_destroy orphans it)
+    g2, _ = small.capture(z8, x8)
+    small.close()
+    with pytest.raises(native.VtError):
+        g2.launch()
+    del g2
 
 
 # ViT-Base kernel-form switches (vitb.hip): the default step folds LayerNorm into qkv / fc1 and runs the qkv projection inside the

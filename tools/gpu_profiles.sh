@@ -14,8 +14,29 @@ for g in G128 G256; do
   gl=$(echo $g | tr A-Z a-z)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$g -- python3 $R/bench.py --geom $g --steps 100 --warmup 20 --no-cpu --no-extra --streams 1 > $O/stats_$g.log 2>&1
   cp $O/stats_$g/*/*kernel_stats.csv $O/r${N}_${gl}_kernel_stats.csv
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track_$g -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 40 > $O/track_$g.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track_$g -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 40 --one-stream > $O/track_$g.log 2>&1
   cp $O/track_$g/*/*kernel_stats.csv $O/r${N}_trackstep_${gl}_kernel_stats.csv
+  # HBM bytes per launch of the tracker step's kernels (FETCH_SIZE / WRITE_SIZE, one pass each; held boxes: the 120-360 px windows of a tracker that follows a target)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/trackpmc_${g}_$c -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 24 --one-stream --hold-boxes > $O/trackpmc_${g}_$c.log 2>&1
+  done
+  python3 - $O $g $N <<'P'
+import csv, glob, sys, collections, json
+O, g, N = sys.argv[1:4]
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{O}/trackpmc_{g}_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                tot[k][c] += float(r["Counter_Value"])
+                if c == "FETCH_SIZE": n[k] += 1
+res = {k: {"dispatches": n[k], "fetch_mb_per_dispatch": round(2 * v["FETCH_SIZE"] * 1024 / max(1, n[k]) / 1e6, 2), "write_mb_per_dispatch": round(v["WRITE_SIZE"] * 1024 / max(1, n[k]) / 1e6, 2)}
+       for k, v in tot.items() if "rocclr" not in k and "at::" not in k}
+res["_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) over tracking/track_batch_demo.py --batch 256 --one-stream --hold-boxes; fetch = 2 x FETCH_SIZE KiB (gfx950: 128-byte requests counted as 64), write = WRITE_SIZE KiB, MB per launch"
+json.dump(res, open(f"{O}/r{N}_trackstep_{g.lower()}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+print(g, json.dumps(res, indent=1)[:1500])
+P
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vitb -- python3 $R/tools/vitb_time.py > $O/stats_vitb.log 2>&1
 cp $O/stats_vitb/*/*kernel_stats.csv $O/r${N}_vitb_kernel_stats.csv

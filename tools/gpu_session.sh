@@ -49,8 +49,24 @@ P
       for c in FETCH_SIZE WRITE_SIZE; do
         (cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $R/tools/vitb_time.py > $O/$c.log 2>&1)
       done
-      python3 tools/pmc_traffic.py $O/FETCH_SIZE $O/WRITE_SIZE > $O/traffic.json 2> $O/traffic.err || tail -3 $O/traffic.err
-      head -c 3000 $O/traffic.json
+      # per-kernel HBM bytes from the two passes, written under $O only (the tracked profiles/ files are installed by tools/install_profiles.py)
+      python3 - $O <<'P'
+import csv, glob, sys, collections, json
+O = sys.argv[1]
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{O}/{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                tot[k][c] += float(r["Counter_Value"])
+                if c == "FETCH_SIZE": n[k] += 1
+res = {k: {"dispatches": n[k], "fetch_kib_per_dispatch": round(v["FETCH_SIZE"] / max(1, n[k]), 1), "write_kib_per_dispatch": round(v["WRITE_SIZE"] / max(1, n[k]), 1),
+           "hbm_bytes_per_dispatch": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / max(1, n[k]))}
+       for k, v in tot.items() if "rocclr" not in k and "at::" not in k}
+json.dump(res, open(f"{O}/traffic.json", "w"), indent=1, sort_keys=True)
+print(json.dumps(res, indent=1)[:3000])
+P
       find $O -name "*.db" -delete ;;
     tests)
       timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -6 $O/pytest.txt ;;

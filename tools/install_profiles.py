@@ -10,7 +10,8 @@ commit = sys.argv[2] if len(sys.argv) > 2 else "?"
 O = os.path.join(ROOT, "gpurun_out", f"r{N}prof")
 P = os.path.join(ROOT, "profiles")
 names = [f"r{N}_g128_kernel_stats.csv", f"r{N}_g256_kernel_stats.csv", f"r{N}_vitb_kernel_stats.csv", f"r{N}_trackstep_g128_kernel_stats.csv",
-         f"r{N}_trackstep_g256_kernel_stats.csv", f"r{N}_g128_pmc_summary.txt", f"r{N}_g256_pmc_summary.txt", "pmc_traffic.json", f"r{N}_bench.json"]
+         f"r{N}_trackstep_g256_kernel_stats.csv", f"r{N}_g128_pmc_summary.txt", f"r{N}_g256_pmc_summary.txt", "pmc_traffic.json", f"r{N}_bench.json",
+         f"r{N}_trackstep_g128_pmc_traffic.json", f"r{N}_trackstep_g256_pmc_traffic.json"]
 for f in names:
     src = os.path.join(O, f)
     if os.path.exists(src):

@@ -109,7 +109,8 @@ struct vt_model {
     DevBuf vlscr;                    // G256 frame-form block kernel (A3): the low pieces of V^T, [B][depth][3][L / 32][64] x 16 B (vt_blocks.h VP2L)
     int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
     int tmpl_form_batch = 0;         // the form batch vt_set_template ran under (the cache holds THAT form's operands)
-    int graphs_captured = 0;         // vt_graph_capture[_steps] calls that succeeded: their graphs hold the forms of their capture
+    int graphs_captured = 0;         // live graphs captured from this model (vt_graph_destroy takes them off again): they hold the forms of their capture
+    std::vector<vt_graph*> graphs;   // those graphs; vt_destroy orphans them, so a graph destroyed after its model touches nothing of it
     DevBuf score, size, offset, pred, hann, conf;
     hipStream_t cap_stream = nullptr;
     hipStream_t side_stream[3] = {nullptr, nullptr, nullptr};   // extra capture streams for graph chains
@@ -141,6 +142,7 @@ struct vt_model {
 struct vt_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    vt_model* owner = nullptr;      // its capture counts in owner->graphs_captured until vt_graph_destroy (the model must outlive its graphs)
 };
 
 namespace {
@@ -1336,6 +1338,8 @@ int vt_create(const vt_config* cfg, vt_model** out) {
 
 void vt_destroy(vt_model* m) {
     if (!m) return;
+    for (vt_graph* g : m->graphs) g->owner = nullptr;      // graphs that outlive their model must not reach into it (they may still be destroyed)
+    m->graphs.clear();
     if (m->vb) vb::destroy(m->vb);
     for (int i = 0; i < 4; ++i) { m->stem_w[i].release(); m->stem_b[i].release(); }
     m->stem_w2k.release();
@@ -1851,6 +1855,7 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
     int nch = m->graph_chains;   // vit_48: default 1; ViT-Base: 0 = auto (two chains from 64 frames up, create_vitb)
     if (nch == 0) nch = (m->vb && B >= 64) ? 2 : 1;
     nch = (nsteps > 1 || !z_dev || !z_dev[0]) ? 1 : std::max(1, std::min({nch, 4, (int)B}));
+    if (m->generic) nch = 1;      // the shape-generic kernels share ONE set of scratch buffers (g_a, g_b, g_x, ...): concurrent chains would race on them
     vt_graph* vg = new vt_graph();
     hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e)); }
@@ -1876,6 +1881,8 @@ int vt_graph_capture_steps(vt_model* m, int32_t nsteps, const float* const* z_de
     if (e != hipSuccess) { delete vg; return fail(VT_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); }
     e = hipGraphInstantiate(&vg->exec, vg->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) { (void)hipGraphDestroy(vg->graph); delete vg; return fail(VT_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+    vg->owner = m;
+    m->graphs.push_back(vg);
     *g = vg;
     ++m->graphs_captured;
     return VT_OK;
@@ -1895,6 +1902,11 @@ void vt_graph_destroy(vt_graph* g) {
     if (!g) return;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->owner) {      // the last graph gone: vt_set_form_batch / vt_set_normalization are free again
+        auto& v = g->owner->graphs;
+        v.erase(std::remove(v.begin(), v.end(), g), v.end());
+        if (g->owner->graphs_captured > 0) --g->owner->graphs_captured;
+    }
     delete g;
 }
 

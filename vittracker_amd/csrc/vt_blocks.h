@@ -262,8 +262,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
     static_assert(!BAL || (WLDS && TPW == 1 && NW == 2 * (NT - 1)), "balanced variant: NT-1 owners + NT-1 guests");
     static_assert(!A3 || BF3, "A3: written for the three-piece forms");
     // A3: 16-byte units per key tile of the K pieces / per feature tile of the V^T pieces.  VP3 = V^T as pieces too (the staged G128 form);
-    // the G256 form (BF3G) has LDS for the K pieces only (90 KiB) beside the fp32 V^T image (60 KiB): q k^T and proj run on the bf16 pipe,
-    // P.V stays on fp32 MFMAs
+    // the G256 form (BF3G) has LDS for the K pieces only (90 KiB) beside 60 KiB for V^T: q k^T and proj run on the bf16 pipe, and so does
+    // P.V since VP2L (below), with V^T's low pieces outside LDS
     constexpr bool VP3 = A3 && BF3L;
     // VP2L (round 5): the G256 form's V^T as pieces after all -- the high and middle pieces take exactly the fp32 image's 60 KiB of LDS, the
     // LOW pieces (used by one of a product's six terms) go through a per-frame, per-block scratch in global memory: written by the wave
