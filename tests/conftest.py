@@ -70,7 +70,7 @@ def load_vitb_case(path):
     from vittracker_amd import synth
     g = dict(np.load(path, allow_pickle=False))
     seed, B = int(g["seed"]), int(g["B"])
-    sd = synth.synth_vitb_state_dict(seed)
+    sd = synth.synth_vitb_state_dict(seed, common_mode=float(g["common_mode"]) if "common_mode" in g else 0.0)
     assert synth.state_checksum(sd) == str(g["state_checksum"]), "synth_vitb_state_dict drifted from the fixture generator"
     z, x = synth.synth_inputs(seed, B, 128, 256)
     return g, sd, z, x

@@ -90,9 +90,9 @@ def build_reference_vitb(ostrack, config):
     return net.eval()
 
 
-def run_case(ostrack, config, hann_mod, seed, B, with_acts):
+def run_case(ostrack, config, hann_mod, seed, B, with_acts, common_mode=0.0):
     net = build_reference_vitb(ostrack, config)
-    sd = synth.synth_vitb_state_dict(seed)
+    sd = synth.synth_vitb_state_dict(seed, common_mode=common_mode)
     missing, unexpected = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     z, x = synth.synth_inputs(seed, B, 128, 256)
@@ -118,7 +118,7 @@ def run_case(ostrack, config, hann_mod, seed, B, with_acts):
     for h in hooks:
         h.remove()
     top2 = lambda m: (lambda srt: srt[:, -1] - srt[:, -2])(np.sort(m.reshape(B, -1), axis=1))  # noqa: E731
-    res = {"model": "vitb", "seed": seed, "B": B, "margin_raw": top2(out["score_map"].numpy()),
+    res = {"model": "vitb", "seed": seed, "B": B, "common_mode": float(common_mode), "margin_raw": top2(out["score_map"].numpy()),
            "margin_hann": top2((win * out["score_map"]).numpy()), "state_checksum": synth.state_checksum(sd), "act_rows": np.array(ACT_ROWS),
            "score_map": out["score_map"].numpy(), "size_map": out["size_map"].numpy(), "offset_map": out["offset_map"].numpy(),
            "pred_boxes": out["pred_boxes"].numpy(), "hann_boxes": hbox.numpy(), "conf": conf.numpy()}
@@ -135,11 +135,17 @@ def main():
     ostrack, config, hann_mod = import_reference_ostrack()
     # bf16 kernels are compared with these fp32 outputs: a fixture is only useful for the bbox comparison when
     # its argmax margins sit well above bf16 noise, so seeds are searched for batches whose margins all exceed 0.03
-    want = [(2, True), (3, False)]
+    # (batch, activations, common-mode offset of the token rows in units of their sigma): the last two are the LayerNorm-fold hazard
+    # cases (round 6) -- every token row rides on an offset of 2 / 6 sigma through all twelve blocks
+    want = [(2, True, 0.0), (3, False, 0.0), (2, True, 2.0), (2, False, 6.0)]
+    if "--only-common-mode" in sys.argv:
+        want = [w for w in want if w[2] != 0.0]
     seed = 0
     while want:
-        B, with_acts = want[0]
-        res = run_case(ostrack, config, hann_mod, seed, B, with_acts)
+        B, with_acts, cm = want[0]
+        if cm != 0.0 and seed < 40:
+            seed = 40          # their own seed range: the plain fixtures keep the seeds (and files) they have
+        res = run_case(ostrack, config, hann_mod, seed, B, with_acts, cm)
         ok = min(res["margin_raw"].min(), res["margin_hann"].min()) > 0.03
         print(f"seed {seed} B {B}: margins raw {np.round(res['margin_raw'], 4)} hann {np.round(res['margin_hann'], 4)} -> {'keep' if ok else 'skip'}")
         seed += 1
@@ -147,7 +153,7 @@ def main():
             continue
         want.pop(0)
         seed_used = seed - 1
-        name = f"ref_vitb_s{seed_used}_b{B}.npz"
+        name = f"ref_vitb_s{seed_used}_b{B}.npz" if cm == 0.0 else f"ref_vitb_cm{int(cm)}_s{seed_used}_b{B}.npz"
         np.savez_compressed(os.path.join(HERE, name), **res)
         sm = np.sort(res["score_map"].reshape(B, -1), axis=1)
         print(f"{name}: score range [{sm.min():.4f}, {sm.max():.4f}], top-2 margins {np.round(sm[:, -1] - sm[:, -2], 4)}, "

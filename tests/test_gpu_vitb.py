@@ -3,13 +3,23 @@
 References: (1) tests/golden/ref_vitb_*.npz = outputs of the reference's own build_ostrack model (fp32),
 (2) the pinned torch oracle (oracle/vitb_oracle_torch.py) for full activations to feed single stages.
 
-Tolerance (stated, bf16): operands are rounded to bf16 (8 significand bits, 2^-9 relative) before every contraction,
-accumulation and the residual stream stay in f32.  Observed on MI355X (tools/vitb_diag.py): relative L2 error of the
-residual stream 1.2e-3 after one block, 3.5e-3 after twelve (max abs 3.2e-2 at |x| <= 8.6); maps <= 1.1e-2 (score / size,
-range [0, 1]) and 2.2e-2 (offset); boxes 1.9e-3 on fixture s26_b2 and 4.5e-3 on s33_b3 (a box's w / h ARE size-map values).  The
-tests hold 2x the observed (round 3; 3x before): rel-L2 7e-3 on activations, 2.2e-2 / 4.4e-2 on maps, 9e-3 on boxes (every fixture's
-argmax margin is >= 0.03, so no argmax flip is excusable).  north_star's 1e-3 applies to
-the fp32 vit_48 path, not to this bf16 one."""
+Tolerance (stated, bf16): operands are rounded to bf16 (8 significand bits: relative rounding error uniform in +-2^-9, rms
+2^-9 / sqrt(3) = 1.13e-3) before every contraction; accumulation, LayerNorm statistics, softmax and the residual stream stay in f32.
+Model: a product of two rounded operands carries sqrt(2) x 1.13e-3 = 1.6e-3 rms relative error; a block puts three contractions in
+series on each branch (qkv -> attention -> proj; fc1 -> fc2) whose outputs are added to a stream about 1.4 x their norm, so a block
+contributes an independent relative error of at most eps_b = 1.6e-3 x sqrt(3) / 1.4 = 2.0e-3 to the residual stream, and independent
+errors add in quadrature:  rel-L2 after n blocks <= TOL_REL(n) = 2.0e-3 x sqrt(n)  (1: 2.0e-3, 4: 4.0e-3, 12: 6.9e-3).  Observed on
+MI355X (tools/vitb_cm_diag.py): 1.16e-3 / 2.23e-3 / 3.42e-3 after 1 / 4 / 12 blocks -- the sqrt(n) law, at 0.58 of the bound.
+The bound does NOT grow with a common-mode offset of the token rows (round 6): the LayerNorm fold (vitb.hip: fold_layernorm) used to
+round a row's common mode with the row -- error x sqrt(1 + mean^2 / var): 2.4 x at fixture cm2 (rows riding on 1.9 sigma), 3 x on the
+maps of cm6 -- until the residual-writing GEMMs began to store the rows' bf16 copy CENTRED on the mean the previous LayerNorm
+statistics found (vb_gemm.h Args::cm; the folded weights' rows sum to zero, so the product is unchanged in exact arithmetic).  With
+it the cm fixtures measure 1.18e-3 / 2.25e-3 / 3.52e-3 against the rows' centred norm -- what VB_LN_FOLD=0 measures -- and hold the
+same tolerances as the plain ones, with no allowance for the offset.
+Maps and boxes: max abs 1.3e-2 (score / size, range [0, 1]) and 3.0e-2 (offset) over the four fixtures, boxes 3.9e-3 / 4.9e-3 (a box's
+w / h ARE size-map values); held at 2.2e-2 / 4.4e-2 on maps and 9e-3 on boxes = the head's four bf16 convolutions on features that carry
+TOL_REL(12) (every fixture's argmax margin is >= 0.03, so no argmax flip is excusable).  north_star's 1e-3 applies to the fp32 vit_48
+path, not to this bf16 one."""
 import os
 
 import numpy as np
@@ -19,7 +29,10 @@ from conftest import load_vitb_case, vitb_golden_files
 
 pytestmark = pytest.mark.gpu
 
-TOL_REL = 7e-3
+def TOL_REL(n):          # the stated bound on the residual stream's relative L2 error after n blocks (module docstring)
+    return 2.0e-3 * (n ** 0.5)
+
+
 TOL_MAP = {"score_map": 2.2e-2, "size_map": 2.2e-2, "offset_map": 4.4e-2}
 TOL_BOX = 9e-3
 
@@ -58,28 +71,40 @@ def test_vitb_forward_matches_reference_golden(path):
         assert torch.equal(getattr(out, k), getattr(o2, k)), k
 
 
-def test_vitb_each_stage_against_reference_activations():
+def _act_fixtures():
+    return [p for p in vitb_golden_files() if "act_norm" in np.load(p).files]
+
+
+@pytest.mark.parametrize("path", _act_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
+def test_vitb_each_stage_against_reference_activations(path):
     """Stage outputs against the activations the REFERENCE model produced (row-subsampled in the fixture), each stage
-    fed the pinned oracle's upstream activation so an error cannot hide behind an upstream one."""
+    fed the pinned oracle's upstream activation so an error cannot hide behind an upstream one.  Fixture cm2 rides every token row on a
+    1.9 sigma common-mode offset: errors there are measured against the rows' CENTRED norm (what a LayerNorm sees) and held to the same
+    bound -- the offset earns no allowance."""
     import torch
     from oracle import vitb_oracle_torch as ob
-    path = [p for p in vitb_golden_files() if "act_norm" in np.load(p).files][0]
     g, sd, z, x = load_vitb_case(path)
     rows = g["act_rows"]
+
+    def rel_c(got, want):       # relative L2 against the centred rows
+        want = np.asarray(want, np.float64)
+        return np.linalg.norm(np.asarray(got, np.float64) - want) / np.linalg.norm(want - want.mean(-1, keepdims=True))
+
     orc = ob.build_from_state(sd)
     acts = {}
     with torch.no_grad():
         orc(torch.from_numpy(z), torch.from_numpy(x), acts)
     m = _model(sd, int(g["B"]))
     tok = m.stem(torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda())
-    assert _rel(tok[:1, rows].cpu().numpy(), g["act_tokens"]) < TOL_REL
+    # the patch embedding is ONE bf16 contraction (K = 768) + an f32 pos-embed add: 1.6e-3 rms by the model above, held at twice that
+    assert rel_c(tok[:1, rows].cpu().numpy(), g["act_tokens"]) < 3.2e-3
     for k in (1, 4, 12):                         # blocks[0..k) from the oracle's tokens
         _, resid = m.blocks(acts["tokens"].cuda().contiguous(), nblocks=k, want_resid=True)
-        assert _rel(resid[:1, rows].cpu().numpy(), g[f"act_block{k - 1}"]) < TOL_REL, k
+        assert rel_c(resid[:1, rows].cpu().numpy(), g[f"act_block{k - 1}"]) < TOL_REL(k), k
     for k in (5, 11):                            # a single block from the oracle's input of that block
         m2 = _model({**sd, **{kk.replace(f"blocks.{k}.", "blocks.0."): v for kk, v in sd.items() if f"backbone.blocks.{k}." in kk}}, int(g["B"]))
         _, resid = m2.blocks(acts[f"block{k - 1}"].cuda().contiguous(), nblocks=1, want_resid=True)
-        assert _rel(resid[:1, rows].cpu().numpy(), g[f"act_block{k}"]) < 3e-3, k
+        assert rel_c(resid[:1, rows].cpu().numpy(), g[f"act_block{k}"]) < TOL_REL(1), k
     feat = m.blocks(acts["block11"].cuda().contiguous(), nblocks=0)          # final norm only: f32 arithmetic
     srows = [r - 64 for r in rows if r >= 64]
     np.testing.assert_allclose(feat[:1, srows].cpu().numpy(), g["act_norm"][:, [i for i, r in enumerate(rows) if r >= 64]], atol=2e-4, rtol=0)

@@ -1,7 +1,7 @@
 """Resource-usage regression gate (round 3 review, item 7): every kernel of the default paths compiles to ScratchSize 0 with no VGPR
 spill and inside the register cap of its workgroup size.  Compiles both translation units with the Makefile's flags and
 `-Rpass-analysis=kernel-resource-usage` (tools/resource_table.py; ~2 min, no GPU needed; skipped where hipcc is absent).  The table
-of the round's last kernel change is profiles/r5_resource_usage.txt: this commit may not use MORE registers or scratch than it says."""
+of the round's last kernel change is profiles/r6_resource_usage.txt: this commit may not use MORE registers or scratch than it says."""
 import os
 import re
 import shutil
@@ -19,19 +19,21 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 # kernels a default run launches at some batch size: (name pattern, VGPR cap of its workgroup size: 512 / waves per SIMD)
 DEFAULT_VIT48 = [
     # large batches (what bench.py times)
-    (r"vts::stem_fused_kernel<[012], false, true>", 128),            # 1024 threads
-    (r"vts::stem_stream_kernel<256, 128, [012]>", 128),
+    (r"vts::stem_fused_kernel<[012], false, true, false>", 128),     # 1024 threads
+    (r"vts::stem_fused_kernel<1, false, (false|true), true>", 128),  # round 6: the tracker step's uint8-patch forms
+    (r"vts::stem_stream_kernel<256, 128, [012], false>", 128), (r"vts::stem_stream_kernel<(256, 128|128, 64), 1, true>", 128),
     (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), true, (false|true)>", 256),       # 512 threads; last flag: A3 (round 5)
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true, false>", 256),       # VT_BLOCKS_BF3=1
     (r"vth3::head_fused3_kernel", 168),                              # 768 threads
     (r"vth3::head_seq3_kernel<8, 2, false>", 256),
     # small batches / the plugin's one-sequence step
-    (r"vts::stem_a_kernel", 256), (r"vts::stem_b_kernel<false>", 256),
+    (r"vts::stem_a_kernel<(false|true)>", 256), (r"vts::stem_b_kernel<false>", 256),
     (r"vtb::tile_qkv_kernel<(5|20)>", 512), (r"vtb::tile_attn_mlp_kernel<(5|20)>", 256),
     (r"vth3::head_towers3_kernel", 256), (r"vth::head_towers_kernel<16, 8, false, (false|true)>", 256), (r"vth::head_conv1_kernel<16>", 256),
-    (r"vth::decode_kernel", 512), (r"vtt::crop_kernel<(false|true)>", 256), (r"vtt::crop_fast_kernel<[124]>", 256), (r"vtt::update_state_kernel", 512),
+    (r"vth::decode_kernel", 512), (r"vtt::crop_kernel<(false|true), (false|true)>", 256), (r"vtt::crop_fast_kernel<[124], (false|true)>", 256),
+    (r"vtt::crop_band_kernel<(false|true), [456], [24], (false|true)>", 256), (r"vtt::update_state_kernel", 512),
     # fp32-MFMA forms selected by VT_*_BF3=0 (bench.py's all-fp32 comparison)
-    (r"vts::stem_fused_kernel<[012], false, false>", 128), (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), false, false>", 256),
+    (r"vts::stem_fused_kernel<[012], false, false, false>", 128), (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), false, false>", 256),
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), false, false>", 256), (r"vth::head_fused_kernel<8, false>", 168),
     (r"vth::head_seq_kernel<16, 8, false>", 256),
 ]
@@ -49,7 +51,7 @@ PARKED = {r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), true, true>
 # the f16 build (BASELINE config 5, -DVT_F16=1): the kernels its default path launches at B = 256 (round 4 advisor: they were printed
 # in the table but never gated)
 DEFAULT_F16 = [
-    (r"vts::stem_fused_kernel<[012], false, (false|true)>", 128), (r"vts::stem_pipe_kernel.*", 256), (r"vts::stem_b_kernel<false>", 256),
+    (r"vts::stem_fused_kernel<[012], false, (false|true), (false|true)>", 128), (r"vts::stem_pipe_kernel.*", 256), (r"vts::stem_b_kernel<false>", 256),
     (r"vtb::blocks_kernel<5, 8, 1, true, true, (false|true), false, false>", 256),
     (r"vtb::blocks_kernel<20, 8, 3, false, false, (false|true), false, false>", 256),
     (r"vth::head_fused_kernel<8, false>", 168), (r"vth::head_seq_kernel<16, 8, false>", 256),
@@ -102,11 +104,11 @@ def test_vitb_kernels(tables):
 
 
 def test_committed_table_is_not_exceeded(tables):
-    """profiles/r5_resource_usage.txt (python tools/resource_table.py > profiles/r5_resource_usage.txt) is a ceiling: a kernel of this
+    """profiles/r6_resource_usage.txt (python tools/resource_table.py > profiles/r6_resource_usage.txt) is a ceiling: a kernel of this
     commit may use fewer registers / less scratch than the table says (another hipcc, a later edit), never more."""
     heads = {"## vittrack.hip": "vittrack", "## vittrack.hip -DVT_F16=1": "vittrack_f16", "## vitb.hip": "vitb"}
     committed, cur = {k: {} for k in heads.values()}, None
-    for ln in open(os.path.join(REPO, "profiles", "r5_resource_usage.txt")):
+    for ln in open(os.path.join(REPO, "profiles", "r6_resource_usage.txt")):
         if ln.startswith("## "):
             cur = heads[ln.strip()]
             continue

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel resource usage of both translation units (the Makefile's flags, `-Rpass-analysis=kernel-resource-usage`): VGPRs,
-ScratchSize, VGPR / SGPR spills, LDS.  `python tools/resource_table.py > profiles/r4_resource_usage.txt`; tests/test_resource_usage.py
+ScratchSize, VGPR / SGPR spills, LDS.  `python tools/resource_table.py > profiles/r6_resource_usage.txt`; tests/test_resource_usage.py
 holds the default-path kernels to ScratchSize 0 and no VGPR spill.  (A kernel may show a non-zero ScratchSize with `VGPRs Spill: 0`
 and no scratch instruction: SGPRs spilled to VGPR lanes reserve a frame that is never touched -- stem_a2.)"""
 import os

@@ -114,6 +114,12 @@ struct Args {
     bf16* xb;             // producer (PATCH / RESID): [M][N] bf16 copy of the rows just written to `resid`; nullptr = none
     f2* stats;            // producer: [tiles_n * WN][ldstats] per-row (sum, centred sum of squares) of each 64-column wave slice
     int ldstats;
+    // producer, round 6: the bf16 copy is written as x - c_row, c_row = cm[cm_mod ? m % cm_mod : m] -- an estimate of the row's mean
+    // (RESID: the mean ln_finalize found for the row BEFORE this update; PATCH: mean of the token's pos-embed row + bias).  The folded
+    // weights' rows sum to zero, so subtracting ANY per-row constant leaves x W'^T unchanged in exact arithmetic; in bf16 it takes the
+    // rows' common mode out of what is rounded: the fold's error stops growing with mean^2 / var (tests/test_gpu_vitb.py, cm fixtures).
+    const float* cm;
+    int cm_mod;
     int dbg;              // timing experiments only (VB_DBG, wrong results by design; 0 in production):
                           // 1 = every tile loads the X panel of tile row 0, 2 = ... the W panel of tile column 0,
                           // 4 = no MFMAs, 8 = no epilogue, 16 = no W staging, 32 = no X staging (wide tile)
@@ -319,7 +325,17 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             // where they are added, every one of a tile's TM row groups waits a whole memory latency per wave
             constexpr int AH = VB_RESID_AHEAD;
             f4 oldq[AH + 1][4];
+            float oc[4];      // the rows' centring constants (Args::cm): ONE set, requested at the top of a row group's iteration and used at its end
+                              // (the same few KB for all twelve column tiles of a row: L1 / L2 hits; a ring of AH + 1 sets spilled 40 B)
             const int ch = lane & 15, r0 = lane >> 4;
+            auto load_c = [&](int j, float (&oc)[4]) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = mw + j * 16 + 4 * t + r0;
+                    const int mc = CHECK ? (m < a.M ? m : a.M - 1) : m;
+                    oc[t] = (a.xb && a.cm) ? a.cm[a.cm_mod ? mc % a.cm_mod : mc] : 0.f;
+                }
+            };
             auto load_old = [&](int j, f4 (&o)[4]) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -333,11 +349,13 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
             };
 #pragma unroll
             for (int j = 0; j < AH && j < TM; ++j) load_old(j, oldq[j]);
+
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
 #pragma unroll
                 for (int i = 0; i < TN; ++i) *reinterpret_cast<f4a*>(ep + l15 * 256 + (((i * 4 + (q4 >> 2)) ^ l15) << 4)) = acc[i][j] + bs[i];
                 if (j + AH < TM) load_old(j + AH, oldq[(j + AH) % (AH + 1)]);
+                load_c(j, oc);
                 f4 (&old)[4] = oldq[j % (AH + 1)];
                 lds_fence();
 #pragma unroll
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_kernel(const Args a) {
                         else st4(a.resid + (size_t)m * a.N + nw + ch * 4, nv);
                     }
                     if (a.xb) {
-                        if (ok) *reinterpret_cast<bf16x4*>(a.xb + (size_t)m * a.N + nw + ch * 4) = to_bf16x4(nv);
+                        if (ok) *reinterpret_cast<bf16x4*>(a.xb + (size_t)m * a.N + nw + ch * 4) = to_bf16x4(nv - splat4(oc[t]));
                         const float s = row16_sum(hsum4(nv));
                         const f4 d = nv - splat4(s * (1.0f / 64.0f));
                         const float m2 = row16_sum(hsum4(d * d));

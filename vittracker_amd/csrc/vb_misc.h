@@ -49,7 +49,7 @@ template <int C>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ resid, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps, int M, int L, int Lz, int F,
                                                         bf16* __restrict__ xn, bf16* __restrict__ map, float* __restrict__ feat,
-                                                        bf16* __restrict__ xb, float* __restrict__ rstd_out) {
+                                                        bf16* __restrict__ xb, float* __restrict__ rstd_out, float* __restrict__ mean_out) {
     static_assert(C % 256 == 0, "C = 64 lanes x float4 x n");
     constexpr int NV = C / 256;
     const int lane = threadIdx.x & 63;
@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         v[i] = ld4(p + i * 256 + lane * 4);
         s += hsum4(v[i]);
-        if (xb) *reinterpret_cast<bf16x4*>(xb + (size_t)row * C + i * 256 + lane * 4) = vbg::to_bf16x4(v[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -72,12 +71,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NV; ++i) {
         v[i] = v[i] - splat4(mean);
         ss += hsum4(v[i] * v[i]);
+        // the raw rows' bf16 copy for the LayerNorm-folded GEMMs, CENTRED (vb_gemm.h Args::cm): the folded weights ignore a per-row constant
+        if (xb) *reinterpret_cast<bf16x4*>(xb + (size_t)row * C + i * 256 + lane * 4) = vbg::to_bf16x4(v[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / C) + eps);
     if (rstd_out) {
-        if (lane == 0) rstd_out[row] = rstd;
+        if (lane == 0) { rstd_out[row] = rstd; if (mean_out) mean_out[row] = mean; }
         if (!xn && !map && !feat) return;
     }
     const int f = row / L, t = row - f * L;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // Per-row rstd from the (sum, centred sum of squares) pairs the residual-writing GEMM epilogues leave per 64-column wave slice
 // (vb_gemm.h): Chan's pairwise update, exact mean first.  stats: [P][ld] float2, P = C / 64.  One thread per row.
 template <int P>
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restrict__ stats, int ld, int M, float eps, float* __restrict__ rstd) {
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restrict__ stats, int ld, int M, float eps, float* __restrict__ rstd,
+                                                          float* __restrict__ mean_out) {      // mean_out: the next residual-writing GEMM centres its bf16 copy on it
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
     vbg::f2 v[P];           // all P pairs requested at once: one memory round trip per row
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const vbg::f2* __restr
         m2 += v[p].y + 64.0f * d * d;
     }
     rstd[m] = 1.0f / sqrtf(m2 * inv_c + eps);
+    if (mean_out) mean_out[m] = mean;
 }
 
 // f32 (B, Lx, C) tokens -> the zero-bordered bf16 map (stage API: vt_head on caller-supplied features)

@@ -71,6 +71,9 @@ struct VbModel {
     bool fold = true;
     bool fused_qkv = true;          // VB_FUSED_QKV: the qkv projection inside the attention kernel (vb_qkvattn.h) instead of qk GEMM + v GEMM + attention
     Buf<float> rstd;
+    Buf<float> rmean;        // per-row mean of the residual stream as of the last finalize: the next producer centres its bf16 copy on it
+    Buf<float> cpos;         // [L]: mean over channels of (pos-embed row + patch bias): the patch GEMM's centring constant per token
+    bool center = true;      // VB_LN_CENTER
     Buf<vbg::f2> stats;
 };
 
@@ -156,10 +159,10 @@ hipError_t allow_lds(K kernel, int bytes) {
 }
 
 int run_layernorm(const float* resid, const float* g, const float* b, int B, hipStream_t st, bf16* xn, bf16* map, float* feat, const Err& E,
-                  bf16* xb = nullptr, float* rstd = nullptr) {
+                  bf16* xb = nullptr, float* rstd = nullptr, float* mean = nullptr) {
     const int M = B * L;
     hipLaunchKernelGGL((vbm::layernorm_kernel<C>), dim3((M + 3) / 4), dim3(256), 0, st, resid, g, b, LN_EPS, M, L, LZ, F, xn, map, feat, xb,
-                       rstd);
+                       rstd, mean);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }
@@ -168,7 +171,7 @@ constexpr int STAT_P = C / 64;       // (sum, M2) pairs per residual row: one pe
 
 int run_finalize(const VbModel* m, size_t r0, int M, hipStream_t st, const Err& E) {
     hipLaunchKernelGGL(vbm::ln_finalize_kernel<STAT_P>, dim3((M + 255) / 256), dim3(256), 0, st, m->stats.p + r0, (int)(m->stats.n / STAT_P), M, LN_EPS,
-                       m->rstd.p + r0);
+                       m->rstd.p + r0, m->rmean.p + r0);
     VB_HIP(hipGetLastError());
     return VT_OK;
 }
@@ -203,6 +206,7 @@ int create(const vt_config* cfg, VbModel** out, std::string* err) {
     m->maxB = cfg->max_batch;
     m->blk.resize(m->depth);
     m->fold = env_int("VB_LN_FOLD", 1) != 0;
+    m->center = env_int("VB_LN_CENTER", 1) != 0;
     m->fused_qkv = env_int("VB_FUSED_QKV", 1) != 0;
     const size_t B = (size_t)cfg->max_batch, M = B * L, P2 = (size_t)(F + 2) * (F + 2);
     hipError_t e = hipSuccess;
@@ -210,7 +214,7 @@ int create(const vt_config* cfg, VbModel** out, std::string* err) {
     A(m->xn, M * C); A(m->resid, M * C); A(m->qk, M * 2 * C); A(m->vt, M * C); A(m->ao, M * C); A(m->hid, M * HID);
     A(m->map0, B * P2 * C); A(m->map1, 3 * B * P2 * HEAD_CH[1]); A(m->map2, 3 * B * P2 * HEAD_CH[2]);
     A(m->map3, 3 * B * P2 * HEAD_CH[3]); A(m->t4, 3 * B * LX * HEAD_CH[4]);
-    A(m->rstd, M); A(m->stats, (size_t)STAT_P * M);
+    A(m->rstd, M); A(m->stats, (size_t)STAT_P * M); A(m->rmean, M);
     // zero borders of the padded maps (kernels only ever write interiors)
     if (e == hipSuccess) e = hipMemset(m->map0.p, 0, m->map0.n * 2);
     if (e == hipSuccess) e = hipMemset(m->map1.p, 0, m->map1.n * 2);
@@ -245,7 +249,7 @@ void destroy(VbModel* m) {
     m->w5.release(); m->b5.release();
     m->xn.release(); m->qk.release(); m->vt.release(); m->ao.release(); m->hid.release(); m->map0.release();
     m->map1.release(); m->map2.release(); m->map3.release(); m->t4.release(); m->resid.release();
-    m->rstd.release(); m->stats.release();
+    m->rstd.release(); m->stats.release(); m->rmean.release(); m->cpos.release();
     delete m;
 }
 
@@ -267,6 +271,19 @@ int load_weights(VbModel* m, const TensorMap& tm, std::string* err) {
         if ((rc = need(tm, bb + "pos_embed_x", (int64_t)LX * C, &p, E))) return rc;
         std::memcpy(pos.data() + (size_t)LZ * C, p, (size_t)LX * C * 4);
         if ((rc = upload_f32(m->pos, pos.data(), pos.size(), E))) return rc;
+        // the patch GEMM's centring constants: a token row is patches W^T + bias + pos row; what is known of its mean before the GEMM runs
+        // is mean(bias) + mean(pos row) (the projection of a normalised patch is zero-mean over channels to first order)
+        const float* bp = nullptr;
+        if ((rc = need(tm, bb + "patch_embed.proj.bias", C, &bp, E))) return rc;
+        double bmean = 0;
+        for (int k = 0; k < C; ++k) bmean += bp[k];
+        std::vector<float> cpos(L);
+        for (int t = 0; t < L; ++t) {
+            double s = 0;
+            for (int k = 0; k < C; ++k) s += pos[(size_t)t * C + k];
+            cpos[t] = (float)((s + bmean) / C);
+        }
+        if ((rc = upload_f32(m->cpos, cpos.data(), cpos.size(), E))) return rc;
     }
     const float scale = 1.0f / std::sqrt((float)HD);     // 0.125: a power of two, folding it into W_q / b_q is exact
     for (int i = 0; i < m->depth; ++i) {
@@ -386,6 +403,7 @@ int stem(VbModel* m, const float* z, const float* x, int B, hipStream_t st, floa
     a.X = patches; a.W = m->wpatch.p; a.bias = m->bpatch.p; a.resid = resid; a.pos = m->pos.p;
     a.M = M; a.N = C; a.K = PATCH_K; a.L = L;
     if (m->fold) { a.xb = xn; a.stats = m->stats.p + r0; a.ldstats = (int)(m->stats.n / STAT_P); }
+    if (m->fold && m->center) { a.cm = m->cpos.p; a.cm_mod = L; }
     if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_PATCH>(a, 1, st, E, cus))) return rc;
     if (m->fold && (rc = run_finalize(m, r0, M, st, E))) return rc;
     if (tokens_out) VB_HIP(hipMemcpyAsync(tokens_out, resid, (size_t)M * C * 4, hipMemcpyDeviceToDevice, st));
@@ -415,7 +433,8 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
     vbg::f2* const stats = m->stats.p + r0;
     const int ldstats = (int)(m->stats.n / STAT_P);
     // folded LayerNorms: a residual stream from outside has no bf16 copy / rstd yet (vb::stem leaves both behind its GEMM)
-    if (fold && tokens_in && nblocks > 0 && (rc = run_layernorm(resid, nullptr, nullptr, B, st, nullptr, nullptr, nullptr, E, xn, rstd))) return rc;
+    const float* const cmean = (fold && m->center) ? m->rmean.p + r0 : nullptr;
+    if (fold && tokens_in && nblocks > 0 && (rc = run_layernorm(resid, nullptr, nullptr, B, st, nullptr, nullptr, nullptr, E, xn, rstd, m->rmean.p + r0))) return rc;
     for (int i = 0; i < nblocks; ++i) {
         const BlockW& b = m->blk[i];
         if (!fold && (rc = run_layernorm(resid, b.ln1g.p, b.ln1b.p, B, st, xn, nullptr, nullptr, E))) return rc;
@@ -442,7 +461,7 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
         }
         vbg::Args p{};
         p.X = ao; p.W = b.wproj.p; p.bias = b.bproj.p; p.resid = resid; p.M = M; p.N = C; p.K = C;
-        if (fold) { p.xb = xn; p.stats = stats; p.ldstats = ldstats; }
+        if (fold) { p.xb = xn; p.stats = stats; p.ldstats = ldstats; p.cm = cmean; }
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(p, 1, st, E, cus))) return rc;
         if (fold ? (rc = run_finalize(m, r0, M, st, E)) : (rc = run_layernorm(resid, b.ln2g.p, b.ln2b.p, B, st, xn, nullptr, nullptr, E))) return rc;
         vbg::Args f1{};
@@ -452,7 +471,7 @@ int blocks(VbModel* m, const float* tokens_in, int B, int nblocks, hipStream_t s
         vbg::Args f2{};
         f2.X = hid; f2.W = b.w2.p; f2.bias = b.b2.p; f2.resid = resid; f2.M = M; f2.N = C; f2.K = HID;
         const bool feeds_ln = fold && i + 1 < nblocks;            // the final norm reads the f32 stream itself
-        if (feeds_ln) { f2.xb = xn; f2.stats = stats; f2.ldstats = ldstats; }
+        if (feeds_ln) { f2.xb = xn; f2.stats = stats; f2.ldstats = ldstats; f2.cm = cmean; }
         if ((rc = launch_gemm<256, 256, 2, 4, vbg::A_PLAIN, vbg::EPI_RESID>(f2, 1, st, E, cus))) return rc;
         if (feeds_ln && (rc = run_finalize(m, r0, M, st, E))) return rc;
     }

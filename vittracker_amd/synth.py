@@ -132,7 +132,7 @@ def state_checksum(sd: dict) -> str:
 
 # ----------------------------------------------------------------------------- ViT-Base (BASELINE config 4)
 def synth_vitb_state_dict(seed: int = 0, C: int = 768, depth: int = 12, heads: int = 12, head_ch: int = 256,
-                          len_z: int = 64, len_x: int = 256, patch: int = 16, mlp_ratio: int = 4) -> dict:
+                          len_z: int = 64, len_x: int = 256, patch: int = 16, mlp_ratio: int = 4, common_mode: float = 0.0) -> dict:
     """Seeded synthetic weights in the OSTrack ``ckpt['net']`` key layout (``backbone.*`` = VisionTransformer,
     lib/models/ostrack/vit.py:94-139 after ``finetune_track``, lib/models/ostrack/base_backbone.py:37-108;
     ``box_head.*`` = CenterPredictor(inplanes=768, channel=256), lib/models/layers/head.py:98-128).
@@ -156,8 +156,11 @@ def synth_vitb_state_dict(seed: int = 0, C: int = 768, depth: int = 12, heads: i
     b = "backbone."
     sd[b + "cls_token"] = np.zeros((1, 1, C), np.float32)
     sd[b + "pos_embed"] = np.zeros((1, 197, C), np.float32)
-    sd[b + "pos_embed_z"] = normal((1, len_z, C), 0.1)
-    sd[b + "pos_embed_x"] = normal((1, len_x, C), 0.1)
+    # common_mode: the same offset on EVERY channel of every token row (in units of the rows' standard deviation, ~1 here): the residual
+    # stream carries it through all twelve blocks, each LayerNorm has to remove it -- the case in which folding LayerNorm's mean
+    # subtraction into the bf16 weights (vitb.hip: fold_layernorm) rounds the common mode with the row (tests/test_gpu_vitb.py)
+    sd[b + "pos_embed_z"] = normal((1, len_z, C), 0.1) + np.float32(common_mode)
+    sd[b + "pos_embed_x"] = normal((1, len_x, C), 0.1) + np.float32(common_mode)
     sd[b + "patch_embed.proj.weight"] = normal((C, 3, patch, patch), (1.0 / (3 * patch * patch)) ** 0.5)
     sd[b + "patch_embed.proj.bias"] = normal((C,), 0.1)
     H, hd = C * mlp_ratio, C // heads
