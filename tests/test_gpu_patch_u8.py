@@ -77,9 +77,12 @@ def test_the_fast_crop_form_is_the_one_this_gpu_runs():
     assert native.crop_form() == 1
 
 
-@pytest.mark.parametrize("env", [{"VT_CROP_BYTES": "1"}, {"VT_CROP_FAST": "0"}])
+@pytest.mark.parametrize("env", [{"VT_CROP_BYTES": "1"}, {"VT_CROP_FAST": "0"}, {"VT_CROP_BAND": "0"}, {"VT_CROP_BAND": "-4"}, {"VT_CROP_BAND": "-2"},
+                                 {"VT_CROP_BAND": "-4", "VT_CROP_ALIGNED": "0"}])
 def test_other_crop_kernel_forms_write_the_same_patch(env):
-    """The byte-load twin and crop_kernel (VT_CROP_FAST=0), each in a child (a process reads the switches once)."""
+    """The byte-load twin, crop_kernel (VT_CROP_FAST=0), crop_fast_kernel at every size (VT_CROP_BAND=0) and crop_band_kernel forced at
+    every batch (-4 / -2: four / two items per thread; VT_CROP_ALIGNED=0: byte-aligned windows) -- the library picks between the last
+    two by how many workgroups the batch gives a CU -- each in a child (a process reads the switches once), uint8 patch AND fp32 crop."""
     import subprocess
     import sys
     code = r"""
@@ -91,12 +94,15 @@ H, W = 37, 53
 boxes = [[rs.uniform(-10, W), rs.uniform(-10, H), rs.uniform(2, 40), rs.uniform(2, 40)] for _ in range(20)] + [[W - 3.5, H - 3.5, 3, 3], [0, 0, W, H], [W - 1, H - 1, 1, 1]]
 frames = rs.randint(0, 256, (len(boxes), H, W, 3)).astype(np.uint8)
 m = T._model(128, len(boxes))
-for S in (64, 128, 20, 30):
+import test_gpu_pipeline as P
+for S in (64, 128, 256, 20, 30):
     patch, rf = m.crop_u8(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), 2.0, S)
-    patch = patch.cpu().numpy()
+    crop, rf2 = m.crop(torch.from_numpy(frames).cuda(), torch.tensor(boxes, dtype=torch.float64).cuda(), 2.0, S, T.MEAN, T.STD)
+    patch, crop = patch.cpu().numpy(), crop.cpu().numpy()
     for b in range(len(boxes)):
         want, want_rf = T._host_patch(frames[b], boxes[b], 2.0, S)
         assert np.array_equal(patch[b], want) and float(rf[b]) == want_rf, (S, boxes[b])
+        assert np.array_equal(crop[b], P._host_crop(frames[b], boxes[b], 2.0, S)[0]) and float(rf2[b]) == want_rf, (S, boxes[b])
 print("FORM-OK")
 """ % (REPO, os.path.join(REPO, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

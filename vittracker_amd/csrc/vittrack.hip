@@ -915,13 +915,20 @@ void launch_crop(bool bytes, const unsigned char* frames, int H, int W, const do
     if (u8out) mean3 = std3 = none3;
     // the tracker's sizes: crop_band_kernel (a workgroup owns a band of VT_CROP_BAND x 256 items; 0: crop_fast_kernel as in round 5)
     static const int band = [] { const char* v = std::getenv("VT_CROP_BAND"); return v && *v ? std::atoi(v) : 4; }();
-    if (!bytes && fast > 0 && band > 0 && (T == 64 || T == 128 || T == 256)) {
+    bool band_ipt2 = false;
+    // ... when its bands fill the chip.  A thread of a band walks its items one after the other, so a few frames are a long dependent chain on a few
+    // CUs: one frame at T = 128 takes 12.1 us as four bands of four items, 8.0 as eight bands of two, 5.4 as sixteen workgroups of
+    // crop_fast_kernel (tools/gpu_b1prof.sh) -- the form follows the number of workgroups the batch gives each CU
+    const long items = (long)B * T * (T / 4);
+    const bool bands_fill = band < 0 || items >= 2L * 256 * 256;      // at least one two-item band (512 items) per CU; VT_CROP_BAND=-4 / -2 force a band form (tests)
+    if (!bytes && fast > 0 && band != 0 && bands_fill && (T == 64 || T == 128 || T == 256)) {
+        if (band > 0 && items < 4L * 256 * 256) band_ipt2 = true;
         auto go = [&](auto kernel, int ipt) {
             hipLaunchKernelGGL(kernel, dim3(T * (T / 4) / (256 * ipt), B), dim3(256), 0, st, frames, H, W, states, factor, mean3[0], mean3[1], mean3[2],
                                std3[0], std3[1], std3[2], crops, rf);
         };
         static const int aligned = [] { const char* v = std::getenv("VT_CROP_ALIGNED"); return v && *v ? std::atoi(v) : 1; }();     // 0: byte-aligned 8-byte windows
-        const int ipt = band >= 4 ? 4 : 2;
+        int ipt = ((band >= 4 || band <= -4) && !band_ipt2) ? 4 : 2;
         auto pick = [&](auto u8c, auto lgc) {
             constexpr bool U = decltype(u8c)::value;
             constexpr int LG = decltype(lgc)::value;
