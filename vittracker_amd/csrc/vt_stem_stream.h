@@ -228,6 +228,7 @@ __global__ __launch_bounds__(1024) void stem_stream_kernel(
             dst[J.npix1 + J.HALF + 1 + qp] = f4{a1[4], a1[5], 0.f, 0.f};
         };
         L1In<U8> va, vb;
+        // (stem_fused's wave-staggered first fetch, NOTES R6-4, measured here too: 88.0 against 88.2-88.3 us -- the start-up is 2 % of this kernel)
         fetch(band(g_lo), va);
         __syncthreads();                 // constants in LDS (the other roles' first reads) -- every role executes this barrier
 #pragma unroll 1
