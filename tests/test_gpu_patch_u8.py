@@ -181,6 +181,32 @@ def test_forward_u8_matches_forward_on_the_normalised_crop(geom, B):
     m.close()
 
 
+@pytest.mark.parametrize("geom,B", [(128, 3), (128, 200), (256, 2)])
+def test_f16_build_reads_patches_too(geom, B):
+    """The f16-contraction build (BASELINE config 5) runs the same uint8 stem forms (layer 1 is fp32 vector work in either build):
+    vt_forward_u8 against the fp32 build's vt_forward on the normalised crop, at the f16 build's tolerance (maps 6e-3, boxes 2e-3)."""
+    import torch
+    from vittracker_amd import native, synth
+    sd = synth.synth_state_dict(3, len_z=(geom // 32) ** 2, len_x=(geom // 16) ** 2)
+    m32 = native.Model(geom // 2, geom, max_batch=B)
+    m32.load_state_dict(sd)
+    m16 = native.Model(geom // 2, geom, max_batch=B, precision="f16")
+    m16.load_state_dict(sd)
+    assert m16.patch_u8_supported(B)
+    patches = torch.from_numpy(synth.synth_patches(13, B, geom)).cuda()
+    z = torch.from_numpy(synth.synth_inputs(13, B, geom // 2, geom)[0]).cuda()
+    x = torch.from_numpy(synth.normalise_patches(patches.cpu().numpy())).cuda()
+    want, got = m32.forward(z, x), m16.forward_u8(z, patches)
+    for k in ("score_map", "size_map", "offset_map"):
+        assert float((getattr(got, k) - getattr(want, k)).abs().max()) < 6e-3, k
+    same = (got.pred_boxes - want.pred_boxes).abs().amax(1) < 2e-3          # frames whose argmax agrees (f16 noise may flip a near tie)
+    assert float(same.float().mean()) >= 0.9
+    m16.set_template(z)
+    cached = m16.forward_u8(None, patches)
+    assert torch.equal(cached.score_map, got.score_map) and torch.equal(cached.pred_boxes, got.pred_boxes)      # the template cache is exact
+    m32.close(); m16.close()
+
+
 def test_forward_u8_with_another_normalisation():
     """vt_set_normalization refolds layer 1: another mean / std against vt_forward on the crop normalised with them."""
     import torch
