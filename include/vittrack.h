@@ -159,11 +159,12 @@ int vt_set_normalization(vt_model* m, const float* mean3, const float* std3);
  * lib/models/vit_dist/vit_dist.py:77-100): x_patch_dev (B,S,S,3) uint8 as vt_crop_u8 writes it; z_dev (B,3,Tz,Tz) fp32 as in
  * vt_forward, or NULL after vt_set_template.  Results agree with vt_forward on the normalised fp32 crop to fp32 rounding (the
  * reference rounds three times per input value, the folded layer once; tests: maps within 1e-5), not bit for bit.
- * Tuned vit_48 geometries only; VT_ERR_STATE when the stem form this batch selects has no uint8 variant (vt_patch_u8_supported). */
+ * vit_48 path (every stem form of the tuned geometries; the shape-generic kernels normalise per tap with the reference's own three
+ * rounded operations and are bit-identical to vt_forward); VT_ERR_STATE under the diagnostic switches (vt_patch_u8_supported). */
 int vt_forward_u8(vt_model* m, const float* z_dev, const uint8_t* x_patch_dev, int32_t B, void* stream, const vt_outputs* out);
 /* The search rows of vt_stem from a uint8 patch: tokens_dev (B,L,C), rows [len_z, L) written, template rows untouched. */
 int vt_stem_u8(vt_model* m, const uint8_t* x_patch_dev, int32_t B, void* stream, float* tokens_dev);
-/* 1 when a batch of B (under the model's form batch) runs a stem form that reads uint8 patches, else 0. */
+/* 1 when a batch of B runs a stem form that reads uint8 patches (every vit_48 form outside the diagnostic builds), else 0 (ViT-Base). */
 int vt_patch_u8_supported(const vt_model* m, int32_t B);
 /* Which crop kernel form the current device runs (decided once per device by a self test against a byte-load twin):
  * 1 = the 8-byte unaligned-window form, 2 = the byte-load form, negative = the self test could not run. */
@@ -189,7 +190,7 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
  * itself (one launch less per step).  record may be NULL.  vit_48 path only.
  * Round 6: the crop reaches the stem as sample_target's uint8 patch -- the step is vt_crop_u8 -> vt_forward_u8(z = NULL) ->
  * vt_update_state_record, bit for bit, and crops_dev holds the (B,S,S,3) uint8 patch in its first bytes -- whenever
- * vt_patch_u8_supported(m, B) and (mean3, std3) equal the model's normalisation (vt_set_normalization); otherwise (and with
+ * (mean3, std3) equal the model's normalisation (vt_set_normalization) and vt_patch_u8_supported(m, B); otherwise (and with
  * VT_TRACK_U8=0 in the environment at vt_create) it is vt_crop -> vt_forward(z = NULL) -> vt_update_state_record with the fp32 crop. */
 int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, double* states_dev, double factor, const float* mean3,
                   const float* std3, int32_t B, void* stream, float* crops_dev, double* resize_factor_dev, const vt_outputs* out,

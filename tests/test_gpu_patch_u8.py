@@ -181,7 +181,7 @@ def test_forward_u8_matches_forward_on_the_normalised_crop(geom, B):
     m.close()
 
 
-@pytest.mark.parametrize("geom,B", [(128, 3), (128, 200), (256, 2)])
+@pytest.mark.parametrize("geom,B", [(128, 3), (128, 200), (256, 2), (256, 180)])
 def test_f16_build_reads_patches_too(geom, B):
     """The f16-contraction build (BASELINE config 5) runs the same uint8 stem forms (layer 1 is fp32 vector work in either build):
     vt_forward_u8 against the fp32 build's vt_forward on the normalised crop, at the f16 build's tolerance (maps 6e-3, boxes 2e-3)."""
@@ -205,6 +205,53 @@ def test_f16_build_reads_patches_too(geom, B):
     cached = m16.forward_u8(None, patches)
     assert torch.equal(cached.score_map, got.score_map) and torch.equal(cached.pred_boxes, got.pred_boxes)      # the template cache is exact
     m32.close(); m16.close()
+
+
+def test_generic_geometry_reads_patches_bit_identically():
+    """A geometry without tuned kernels (112 / 224 px: 245 tokens) runs vt_generic.h, whose uint8 stem layer normalises every tap with
+    the reference's own three rounded operations: vt_forward_u8 == vt_forward on the normalised crop, bit for bit."""
+    import torch
+    from vittracker_amd import native, synth
+    tz, tx, B = 112, 224, 3
+    m = native.Model(tz, tx, max_batch=B)
+    m.load_state_dict(synth.synth_state_dict(6, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2))
+    assert m.patch_u8_supported(B)
+    patches = torch.from_numpy(synth.synth_patches(14, B, tx)).cuda()
+    z = torch.from_numpy(synth.synth_inputs(14, B, tz, tx)[0]).cuda()
+    x = torch.from_numpy(synth.normalise_patches(patches.cpu().numpy())).cuda()
+    want, got = m.forward(z, x), m.forward_u8(z, patches)
+    for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+        assert torch.equal(getattr(got, k), getattr(want, k)), k
+    m.set_template(z)
+    cached = m.forward_u8(None, patches)
+    assert torch.equal(cached.score_map, want.score_map)
+    m.close()
+
+
+def test_stem_pipe_reads_patches():
+    """VT_STEM_STREAM=0 at G256 and a large batch selects stem_pipe + stem_b in the fp32 build (the f16 build's default there): its uint8
+    form against vt_forward on the normalised crop, in a child (the switch is read at vt_create... per process for safety)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from vittracker_amd import native, synth
+geom, B = 256, 180
+m = native.Model(geom // 2, geom, max_batch=B)
+m.load_state_dict(synth.synth_state_dict(3, len_z=64, len_x=256))
+patches = torch.from_numpy(synth.synth_patches(15, B, geom)).cuda()
+z = torch.from_numpy(synth.synth_inputs(15, B, geom // 2, geom)[0]).cuda()
+x = torch.from_numpy(synth.normalise_patches(patches.cpu().numpy())).cuda()
+m.set_template(z)
+want, got = m.forward(None, x), m.forward_u8(None, patches)
+for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes"):
+    err = float((getattr(got, k) - getattr(want, k)).abs().max())
+    assert err < 1e-5, (k, err)
+print("PIPE-OK")
+""" % REPO
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VT_STEM_STREAM="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "PIPE-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_forward_u8_with_another_normalisation():

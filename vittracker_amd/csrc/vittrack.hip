@@ -416,7 +416,7 @@ StemPlan stem_plan_default(int T) {
 // ---------------------------------------------------------------------------------------- shape-generic path (vt_generic.h)
 inline unsigned gen_grid(size_t n) { return (unsigned)((n + 255) / 256); }
 
-int gen_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, int zmode) {
+int gen_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, int zmode, bool xu8 = false) {
     for (int side = 0; side < 2; ++side) {       // 0: template rows, 1: search rows
         const float* img = side == 0 ? z : x;
         if ((side == 0 && zmode == 1) || (side == 1 && zmode == 2) || !img) continue;
@@ -427,6 +427,14 @@ int gen_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
             const int cin = STEM_CH[i], cout = STEM_CH[i + 1], So = S / 2;
             float* out = (i & 1) ? m->g_b.p : m->g_a.p;
             const size_t total = (size_t)B * cout * So * So;
+            if (i == 0 && side == 1 && xu8) {      // the search crop arrives as sample_target's uint8 patch: Preprocessor.process per tap, same weights
+                hipLaunchKernelGGL(vtg::stem_conv_u8_kernel, dim3(gen_grid(total)), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(img), m->g_stem_w[0].p,
+                                   m->g_stem_b[0].p, B, cout, S, m->norm_mean[0], m->norm_mean[1], m->norm_mean[2], m->norm_std[0], m->norm_std[1],
+                                   m->norm_std[2], out);
+                in = out;
+                S = So;
+                continue;
+            }
             hipLaunchKernelGGL(vtg::stem_conv_kernel, dim3(gen_grid(total)), dim3(256), 0, st, in, m->g_stem_w[i].p, m->g_stem_b[i].p, B, cin, cout, S,
                                i < 3 ? out : nullptr, i < 3 ? nullptr : tokens, side == 0 ? m->pos_z.p : m->pos_x.p, m->L, side == 0 ? 0 : m->len_z);
             in = out;
@@ -476,19 +484,13 @@ int gen_head(vt_model* m, const float* feat, int B, hipStream_t st, float* score
     return VT_OK;
 }
 
-// Does the stem form a batch of B (under the model's form batch) selects read uint8 patches?  stem_fused, stem_stream and stem_a do;
-// stem_pipe (G256, f16 build or VT_STEM_STREAM=0 at large batches), the diagnostic builds and the shape-generic kernels do not.
+// Does the stem form a batch of B (under the model's form batch) selects read uint8 patches?  Every form of the tuned geometries does
+// (stem_fused, stem_stream, stem_pipe, stem_a); the diagnostic builds and the shape-generic kernels do not.
 bool stem_takes_u8(const vt_model* m, int B) {
-    if (m->generic || m->vb || !m->stem_w1u.p) return false;
-    if (m->skip_stem_a != 0 || m->skip_stem_b != 0 || m->dbg_stamps != nullptr) return false;
-    const int Tx = m->cfg.search_size, Tz = m->cfg.template_size, Bf = form_b(m, B);
-    const bool g256 = Tx == 256 && Tz == 128, g128 = Tx == 128 && Tz == 64;
-#ifndef VT_F16
-    if (m->stem_stream < 0 ? (g256 && Bf > 176) : (m->stem_stream != 0 && (g256 || g128))) return true;
-#endif
-    if ((m->stem_fused < 0 ? Bf > 80 : m->stem_fused != 0) && g128) return true;
-    if ((m->stem_pipe < 0 ? Bf > 176 : m->stem_pipe != 0) && g256) return false;
-    return true;       // stem_a + stem_b
+    (void)B;
+    if (m->vb) return false;
+    if (m->generic) return true;       // vt_generic.h: stem_conv_u8_kernel (the reference's own normalisation per tap)
+    return m->stem_w1u.p != nullptr && m->skip_stem_a == 0 && m->skip_stem_b == 0 && m->dbg_stamps == nullptr;
 }
 
 int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st, float* tokens, size_t f0 = 0, int zmode = 0, bool xu8 = false) {
@@ -496,9 +498,9 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
     // zmode 0: both crops; 1: search crop only (template token rows already in `tokens`); 2: template crop only
     // xu8: x is a uint8 (B, Tx, Tx, 3) patch (vt_crop_u8) and layer 1 runs on the folded weights w1u; zmode 1 only
     if (xu8 && (zmode != 1 || !stem_takes_u8(m, B))) return fail(VT_ERR_STATE, "this stem form has no uint8-patch variant");
+    if (m->generic) return gen_stem(m, z, x, B, st, tokens, zmode, xu8);
     const float* const w1 = xu8 ? m->stem_w1u.p : m->stem_w[0].p;
     const float* const b1 = xu8 ? m->stem_w1u.p + vts::W1U_BIAS : m->stem_b[0].p;
-    if (m->generic) return gen_stem(m, z, x, B, st, tokens, zmode);
     const int Tx = m->cfg.search_size, Tz = m->cfg.template_size;
     float* const act_x = m->act_x.p + f0 * (size_t)(Tx / 4) * (Tx / 4) * 12;
     float* const act_z = m->act_z.p + f0 * (size_t)(Tz / 4) * (Tz / 4) * 12;
@@ -576,11 +578,12 @@ int run_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         constexpr size_t lds_p = vts::PipeGeo<256, 128>::LDS_BYTES;
         const bool diag = m->skip_stem_a != 0 || m->dbg_stamps != nullptr;
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds_p, st, z, x, m->stem_w[0].p, m->stem_b[0].p, m->stem_w[1].p,
+            hipLaunchKernelGGL(kernel, dim3(B), dim3(1024), lds_p, st, z, x, w1, b1, m->stem_w[1].p,
                                m->stem_b[1].p, act_z, act_x, m->skip_stem_a, m->dbg_stamps, m->stem_w2k.p);
         };
         if (diag && zmode != 0) return fail(VT_ERR_STATE, "the diagnostic stem build has no template-cache form");
         if (diag) go(&vts::stem_pipe_kernel<256, 128, 0, true>);
+        else if (xu8) go(&vts::stem_pipe_kernel<256, 128, 1, false, true>);
         else if (zmode == 0) go(&vts::stem_pipe_kernel<256, 128, 0, false>);
         else if (zmode == 1) go(&vts::stem_pipe_kernel<256, 128, 1, false>);
         else go(&vts::stem_pipe_kernel<256, 128, 2, false>);
@@ -1104,6 +1107,7 @@ static hipError_t allow_stem_lds() {
     allow(&vts::stem_pipe_kernel<256, 128, 1, false>, lp);
     allow(&vts::stem_pipe_kernel<256, 128, 2, false>, lp);
     allow(&vts::stem_pipe_kernel<256, 128, 0, true>, lp);
+    allow(&vts::stem_pipe_kernel<256, 128, 1, false, true>, lp);
     allow(&vts::stem_fused_kernel<0, false>, lf);
     allow(&vts::stem_fused_kernel<1, false>, lf);
     allow(&vts::stem_fused_kernel<2, false>, lf);
@@ -1719,12 +1723,12 @@ int vt_crop_u8(vt_model* m, const uint8_t* frames_dev, int32_t H, int32_t W, con
 
 int vt_set_normalization(vt_model* m, const float* mean3, const float* std3) {
     if (!m || !mean3 || !std3) return fail(VT_ERR_ARG, "null argument");
-    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    if (m->vb) return fail(VT_ERR_ARG, "uint8 patches are implemented for the vit_48 path only");
     for (int c = 0; c < 3; ++c)
         if (!(std3[c] > 0.f) || !std::isfinite(mean3[c]) || !std::isfinite(std3[c])) return fail(VT_ERR_ARG, "bad mean / std");
     if (m->graphs_captured > 0 && (std::memcmp(mean3, m->norm_mean, 12) != 0 || std::memcmp(std3, m->norm_std, 12) != 0))
         return fail(VT_ERR_STATE, "captured graphs read the folded layer-1 weights: set the normalisation before capturing");
-    if (!m->weights_loaded) {      // remembered; vt_load_weights folds with these
+    if (!m->weights_loaded || m->generic) {      // remembered: vt_load_weights folds with these; the shape-generic stem takes them as kernel arguments (not in captured graphs: see above)
         std::memcpy(m->norm_mean, mean3, 12);
         std::memcpy(m->norm_std, std3, 12);
         return VT_OK;
@@ -1753,7 +1757,7 @@ int vt_stem_u8(vt_model* m, const uint8_t* x_patch_dev, int32_t B, void* stream,
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!x_patch_dev || !tokens_dev) return fail(VT_ERR_ARG, "null device pointer");
-    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    if (m->vb) return fail(VT_ERR_ARG, "uint8 patches are implemented for the vit_48 path only");
     return run_stem(m, nullptr, reinterpret_cast<const float*>(x_patch_dev), B, static_cast<hipStream_t>(stream), tokens_dev, 0, 1, true);
 }
 
@@ -1761,7 +1765,7 @@ int vt_forward_u8(vt_model* m, const float* z_dev, const uint8_t* x_patch_dev, i
     int rc = check_ready(m, B);
     if (rc) return rc;
     if (!x_patch_dev) return fail(VT_ERR_ARG, "null device pointer");
-    if (m->vb || m->generic) return fail(VT_ERR_ARG, "uint8 patches are implemented for the tuned vit_48 geometries only");
+    if (m->vb) return fail(VT_ERR_ARG, "uint8 patches are implemented for the vit_48 path only");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float* const xu = reinterpret_cast<const float*>(x_patch_dev);
     if (!z_dev) {     // cached template: the tracker step's network part

@@ -88,6 +88,46 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     else out[idx] = hardswish(acc);
 }
 
+// Layer 1 of the stem from the tracker step's uint8 patch (round 6): in = (B, S, S, 3) uint8 HWC, sample_target's return value.  Each tap is
+// normalised as Preprocessor.process does it (lib/test/tracker/data_utils.py:14: three separately rounded fp32 operations, `/ 255.0` as the
+// multiplication by the float reciprocal a GPU torch runs) and meets the SAME weights as stem_conv_kernel: the result is bit-identical to
+// vt_crop + stem_conv_kernel.  One thread per output value, as everything in this file.
+__global__ __launch_bounds__(256) void stem_conv_u8_kernel(const unsigned char* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int B, int Cout, int S, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                           float* __restrict__ out) {
+    const int So = S / 2;
+    const size_t total = (size_t)B * Cout * So * So;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % So);
+    size_t r_ = idx / So;
+    const int oy = (int)(r_ % So);
+    r_ /= So;
+    const int oc = (int)(r_ % Cout), b = (int)(r_ / Cout);
+    const float meanv[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    float acc = bias[oc];
+    for (int ic = 0; ic < 3; ++ic) {
+        const float* wk = w + ((size_t)oc * 3 + ic) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = 2 * oy + r - 1;
+            if (iy < 0 || iy >= S) continue;
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int ix = 2 * ox + sx - 1;
+                if (ix < 0 || ix >= S) continue;
+                float v = (float)in[(((size_t)b * S + iy) * S + ix) * 3 + ic] * (1.0f / 255.0f);
+                asm volatile("" : "+v"(v));          // three roundings, as three torch kernels: no contraction into an fma
+                v = v - meanv[ic];
+                asm volatile("" : "+v"(v));
+                v = v / stdv[ic];
+                acc = fmaf(v, wk[r * 3 + sx], acc);
+            }
+        }
+    }
+    out[idx] = hardswish(acc);
+}
+
 // out[row][o] = act(LN_plain(x[row]) . W[o] + bias[o]); the LayerNorm's affine part is folded into W / bias.  ACT: 0 none, 1 GELU(erf)
 template <int ACT>
 __global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,

@@ -708,7 +708,7 @@ struct PipeGeo {
     static_assert((R2X * (TX / 4)) == 256 && (R2Z * (TZ / 4)) == 256, "16 layer-2 tiles per band");
 };
 
-template <int TX, int TZ, int ZMODE, bool DIAG>
+template <int TX, int TZ, int ZMODE, bool DIAG, bool U8 = false>      // U8 (ZMODE 1): xin is the uint8 (B, TX, TX, 3) patch, w1g / b1 the folded image (vt_stem.h: L1In)
 __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ zin, const float* __restrict__ xin, const float* __restrict__ w1g, const float* __restrict__ b1,
     const float* __restrict__ w2img, const float* __restrict__ b2, float* __restrict__ act_z, float* __restrict__ act_x, int skip_arg,
@@ -716,6 +716,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     const float* __restrict__ w2k) {             // layer-2 weights as [tap][input channels 0-3 | 4-5 + padding][16 output channels][4] (f32 build)
     // ZMODE 0: both crops; 1: search bands only (template cached downstream); 2: template bands only.  DIAG: see stem_fused_kernel.
     using G = PipeGeo<TX, TZ>;
+    static_assert(!U8 || ZMODE == 1, "the uint8 patch form is the search-only (cached template) step");
     const int skip = DIAG ? skip_arg : 0;
     constexpr int s_lo = ZMODE == 1 ? G::NBZ / 2 : 0, s_hi = ZMODE == 2 ? G::NBZ / 2 : G::NB / 2;   // band pairs [s_lo, s_hi)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
@@ -752,11 +753,21 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
     };
     // buffer loads: scalar descriptor + one 32-bit offset register per kernel row pair (see stem_fused_kernel)
     const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zin + (size_t)b * 3 * TZ * TZ), 0, 3 * TZ * TZ * 4, 0x00020000);
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX * 4, 0x00020000);
-    auto fetch = [&](const Band& J, f4 (&v)[3][3]) {           // raw loads only (see stem_fused_kernel)
+    const auto rsrc_x = U8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(xin) + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX, 0x00020000)
+                           : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin + (size_t)b * 3 * TX * TX), 0, 3 * TX * TX * 4, 0x00020000);
+    auto fetch = [&](const Band& J, L1In<U8>& vin) {           // raw loads only (see stem_fused_kernel)
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const int p1 = 2 * J.p0 - 1 + lr;
+        if constexpr (U8) {     // row y, pixels 4 qp .. 4 qp + 3 of the uint8 patch = bytes 12 (y T / 4 + qp) .. + 11: one load per kernel row
+            const unsigned o1 = 12u * ((((unsigned)(2 * p1)) << (J.lgT - 2)) + (unsigned)qp);
+            const unsigned o0 = p1 > 0 ? o1 - (3u << J.lgT) : o1;
+            vin.v[0] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o0, 0, 0);
+            vin.v[1] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1, 0, 0);
+            vin.v[2] = __builtin_amdgcn_raw_buffer_load_b96(rsrc_x, o1 + (3u << J.lgT), 0, 0);
+            return;
+        } else {
+        auto& v = vin.v;
         const unsigned off1 = ((((unsigned)(2 * p1)) << J.lgT) + 4u * (unsigned)qp) << 2;
         const unsigned off0 = p1 > 0 ? off1 - (4u << J.lgT) : off1;
         const unsigned off2 = off1 + (4u << J.lgT);
@@ -768,8 +779,9 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
                 const u4 t = J.is_z ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo, so, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, vo, so, 0);
                 v[r][c] = __builtin_bit_cast(f4, t);
             }
+        }
     };
-    auto layer1 = [&](const Band& J, const f4 (&v)[3][3]) {
+    auto layer1 = [&](const Band& J, const L1In<U8>& vin) {
         __builtin_amdgcn_s_setprio(3);
         const int lr = 1 + (pair >> J.lgHALF), qp = pair & (J.HALF - 1);
         const float keep0 = (2 * J.p0 - 1 + lr) > 0 ? 1.f : 0.f;
@@ -793,9 +805,17 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
             float (&nxt)[18] = (sec & 1) ? wa : wb;
             if (sec + 1 < 9) load_section(nxt, w1g, sec + 1);
             const int r = sec / 3, c = sec % 3;
-            const f4 vv = (r == 0 && J.p0 == 0) ? v[r][c] * splat4(keep0) : v[r][c];     // only the band at the image top has a padding row
+            f4 vv;
+            float padv = 0.f;                                 // what a tap outside the crop reads (fp32 form: the zero padding itself)
+            if constexpr (U8) {
+                padv = b1[W1U_PAD - W1U_BIAS + c];            // 255 mean_c: normalises to zero
+                vv = l1_channel(vin.v[r], c);
+                if (r == 0 && J.p0 == 0 && keep0 == 0.f) vv = splat4(padv);
+            } else {
+                vv = (r == 0 && J.p0 == 0) ? vin.v[r][c] * splat4(keep0) : vin.v[r][c];     // only the band at the image top has a padding row
+            }
             const float left = lane_left(vv.w);
-            const float t0[3] = {qp > 0 ? left : 0.f, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
+            const float t0[3] = {qp > 0 ? left : padv, vv.x, vv.y}, t1[3] = {vv.y, vv.z, vv.w};
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -896,7 +916,7 @@ __global__ __launch_bounds__(1024) void stem_pipe_kernel(
         }
     };
     stamp();
-    f4 v[3][3];
+    L1In<U8> v;
     fetch(band(2 * s_lo + grp), v);
 #ifndef VT_F16
     if (threadIdx.x < 9 * 32) cw2[threadIdx.x] = ld4(w2k + 4 * threadIdx.x);     // [tap][2][16][4] floats
