@@ -42,15 +42,19 @@ typedef struct vt_graph vt_graph;
  *
  * SUPPORTED SHAPES.  The reference builds from any cfg (lib/models/vit_dist/vit_dist.py:159-198; lib/utils/ce_utils.py:22-32 lists
  * template feature sizes 8 / 12 / 7 / 14).  vt_create accepts:
- *     channels 48,  heads 1,  head_channels 32,  stride 16, depth 1..12, (template, search) = ANY multiples of 16 in [16, 512]  -- vit_48_h32
- *         (64, 128) and (128, 256): the tuned kernels (every form of DESIGN.md section 4: MFMA, LDS-resident maps, hipGraph-sized forms)
- *         every other geometry -- e.g. (112, 224), (192, 384); token counts need not be multiples of 16 -- runs the shape-generic
- *         kernels of vt_generic.h: plain fp32, one thread per output value, reference-implementation speed, the same outputs and the
- *         whole ABI (stages, template cache, graphs, vt_crop / vt_track_step)
+ *     stride 16, depth 1..12, (template, search) = ANY multiples of 16 in [16, 512], and (round 6) ANY widths:
+ *         channels a multiple of 8 (the stem's widths are C/8, C/4, C/2, C), heads dividing channels (head dimension <= 256),
+ *         head_channels a multiple of 8 (the towers' widths are W, W/2, W/4, W/8)
+ *     The shipped widths (channels 48, heads 1, head_channels 32) at (64, 128) and (128, 256) run the tuned kernels (every form of
+ *     MFMA, LDS-resident maps, hipGraph-sized forms).  Every other geometry -- e.g. (112, 224), (192, 384); token
+ *     counts need not be multiples of 16 -- and every other width -- e.g. 64 / 2 / 64 -- runs the shape-generic kernels of vt_generic.h:
+ *     plain fp32, one thread per output value, reference-implementation speed, the same outputs (held to the reference's own outputs at
+ *     two other width triples: tests/golden/make_golden_cfg.py) and the whole ABI (stages, template cache, graphs, vt_crop / vt_track_step,
+ *     uint8 patches).
  *     channels 768, heads 12, head_channels 256, stride 16, (template, search) = (128, 256), depth 12                   -- ViT-Base
- * and rejects every other combination with VT_ERR_ARG and a message naming these.  The tuned kernels are specialised on their tile
+ * and rejects everything else with VT_ERR_ARG and a message naming these.  The tuned kernels are specialised on their tile
  * counts (token tiles per frame, feature chunks, map sides are template parameters -- that is where their register blocking comes
- * from), so `heads` and the crop sizes are NOT run-time parameters of THOSE kernels. */
+ * from), so widths and crop sizes are NOT run-time parameters of THOSE kernels. */
 typedef struct vt_config {
     int32_t template_size; /* DATA.TEMPLATE.SIZE  (128; 64 for G128) */
     int32_t search_size;   /* DATA.SEARCH.SIZE    (256; 128 for G128) */
@@ -85,9 +89,9 @@ const char* vt_last_error(void);
 const char* vt_version(void);
 
 /* build_ostrack_dist(cfg) + .cuda() on the current device (vit_dist.py:159-164;
- * lib/test/tracker/vit_dist.py:24-28).  Supported: channels 48, heads 1, head_channels 32, stride 16,
- * (template,search) in {(64,128), (128,256)} (the shipped vit_48_h32; fp32, or f16 contractions in
- * libvittrack_hip_f16.so), and channels 768, heads 12, head_channels 256, (128,256): the OSTrack-256 ViT-Base
+ * lib/test/tracker/vit_dist.py:24-28).  Supported: see SUPPORTED SHAPES above (the shipped vit_48_h32 on tuned kernels -- fp32, or
+ * f16 contractions in libvittrack_hip_f16.so --, any other widths / stride-16 geometry on the shape-generic fp32 kernels), and
+ * channels 768, heads 12, head_channels 256, (128,256): the OSTrack-256 ViT-Base
  * (lib/models/ostrack/ostrack.py:164-286 with lib/models/ostrack/vit.py:94-139; bf16 contractions). */
 int vt_create(const vt_config* cfg, vt_model** out);
 void vt_destroy(vt_model* m);

@@ -35,6 +35,24 @@ def load_case(path):
     return g, sd, z, x
 
 
+def cfg_golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "ref_cfg_*.npz")))
+
+
+def load_cfg_case(path):
+    """(fixture, state dict, z, x, (channels, heads, head_channels)) of a config-surface golden file (tests/golden/make_golden_cfg.py):
+    the reference model built with other CHANNELS / HEADS / HEAD.NUM_CHANNELS than the shipped YAML's."""
+    from vittracker_amd import synth
+    g = dict(np.load(path, allow_pickle=False))
+    geom, seed, B = str(g["geom"]), int(g["seed"]), int(g["B"])
+    C, heads, W = int(g["channels"]), int(g["heads"]), int(g["head_channels"])
+    tz, tx = GEOMS[geom]
+    sd = synth.synth_state_dict(seed, C=C, depth=3, head_ch=W, len_z=(tz // 16) ** 2, len_x=(tx // 16) ** 2)
+    assert synth.state_checksum(sd) == str(g["state_checksum"]), "synth_state_dict drifted from the fixture generator"
+    z, x = synth.synth_inputs(seed, B, tz, tx)
+    return g, sd, z, x, (C, heads, W)
+
+
 def u8_golden_files():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "ref_u8_*.npz")))
 

@@ -85,3 +85,70 @@ def test_sizes_that_are_not_multiples_of_16_are_rejected():
     from vittracker_amd import native
     with pytest.raises(native.VtError, match="multiples of 16"):
         native.Model(100, 200, max_batch=1)
+
+
+def test_other_widths_match_the_reference():
+    """Round 6: CHANNELS / HEADS / HEAD.NUM_CHANNELS other than the shipped 48 / 1 / 32 (build_ostrack_dist takes all three from the YAML,
+    lib/models/vit_dist/vit_dist.py:159-164) run the shape-generic kernels at run-time widths: the REFERENCE model's outputs at 64 / 2 / 64
+    (G256) and 32 / 4 / 16 (G128) -- tests/golden/make_golden_cfg.py -- within the fp32 path's tolerances; template cache, graph replay and
+    the uint8-patch entry included."""
+    import torch
+    from conftest import cfg_golden_files, load_cfg_case
+    from vittracker_amd import native, synth
+    files = cfg_golden_files()
+    assert len(files) == 2
+    for path in files:
+        g, sd, z, x, (C, heads, W) = load_cfg_case(path)
+        B, tz, tx = z.shape[0], z.shape[2], x.shape[2]
+        m = native.Model(tz, tx, channels=C, heads=heads, head_channels=W, max_batch=B)
+        assert m.channels == C
+        m.load_state_dict(sd)
+        zd, xd = torch.from_numpy(z).cuda(), torch.from_numpy(x).cuda()
+        out = m.forward(zd, xd)
+        for k in ("score_map", "size_map", "offset_map"):
+            err = float(np.abs(getattr(out, k).cpu().numpy() - g[k]).max())
+            assert err < 1e-4, (k, C, heads, W, err)
+        for k in ("pred_boxes", "hann_boxes"):
+            got = getattr(out, k).cpu().numpy()
+            assert float(np.abs(got - g[k].reshape(got.shape)).max()) < 1e-5, (k, C, heads, W)
+        m.set_template(zd)
+        cached = m.forward(None, xd)
+        graph, gout = m.capture(None, xd)
+        graph.launch()
+        torch.cuda.synchronize()
+        for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+            assert torch.equal(getattr(cached, k), getattr(out, k)) and torch.equal(getattr(gout, k), getattr(out, k)), k
+        patches = torch.from_numpy(synth.synth_patches(3, B, tx)).cuda()
+        xn = torch.from_numpy(synth.normalise_patches(patches.cpu().numpy())).cuda()
+        assert torch.equal(m.forward_u8(zd, patches).score_map, m.forward(zd, xn).score_map)
+        m.close()
+
+
+def test_model_level_surface_builds_other_widths_from_the_yaml_fields():
+    """build_ostrack_dist(cfg) with MODEL.BACKBONE.CHANNELS / HEADS and MODEL.HEAD.NUM_CHANNELS changed, load_state_dict, forward(z=, x=):
+    the reference's model-level calls (lib/test/tracker/vit_dist.py:24-28, :95-98) at 64 / 2 / 64 against the reference's outputs."""
+    import os
+    import torch
+    from conftest import REPO, cfg_golden_files, load_cfg_case
+    from vittracker_amd import config
+    from vittracker_amd.model import build_ostrack_dist
+    path = [p for p in cfg_golden_files() if "c64h2w64" in p][0]
+    g, sd, z, x, (C, heads, W) = load_cfg_case(path)
+    c = config.fresh_cfg()
+    config.update_config_from_file(os.path.join(REPO, "experiments/vit_dist/vit_48_h32_noKD.yaml"), c)
+    c.MODEL.BACKBONE.CHANNELS, c.MODEL.BACKBONE.HEADS, c.MODEL.HEAD.NUM_CHANNELS = C, heads, W
+    net = build_ostrack_dist(c, max_batch=z.shape[0])
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=False)
+    assert not missing and not unexpected
+    net = net.cuda().eval()
+    out = net.forward(z=torch.from_numpy(z).cuda(), x=torch.from_numpy(x).cuda())
+    for k in ("score_map", "size_map", "offset_map"):
+        assert float(np.abs(out[k].cpu().numpy() - g[k]).max()) < 1e-4, k
+    assert float(np.abs(out["pred_boxes"].cpu().numpy().reshape(-1, 4) - g["pred_boxes"].reshape(-1, 4)).max()) < 1e-5
+
+
+def test_unsupported_widths_are_rejected_with_a_message():
+    from vittracker_amd import native
+    for kw in (dict(channels=50), dict(channels=48, heads=5), dict(head_channels=20), dict(channels=2048, heads=1)):
+        with pytest.raises(native.VtError, match="unsupported model"):
+            native.Model(64, 128, max_batch=1, **kw)

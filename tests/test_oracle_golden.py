@@ -76,6 +76,19 @@ def test_numpy_oracle_matches_reference_on_uint8_patches():
         assert onp.top2_margin(g["score_map"]).min() > 4e-4
 
 
+def test_numpy_oracle_matches_reference_at_other_widths():
+    """Other points of the config surface build_ostrack_dist accepts (CHANNELS / HEADS / HEAD.NUM_CHANNELS = 64 / 2 / 64 and 32 / 4 / 16:
+    tests/golden/make_golden_cfg.py): the oracle is shape-generic, the fixtures pin it there too."""
+    from conftest import cfg_golden_files, load_cfg_case
+    files = cfg_golden_files()
+    assert len(files) == 2, "config-surface fixtures missing"
+    for path in files:
+        g, sd, z, x, (C, heads, W) = load_cfg_case(path)
+        out = onp.forward(sd, z, x, num_heads=heads)
+        for k in ("score_map", "size_map", "offset_map", "pred_boxes", "hann_boxes", "conf"):
+            np.testing.assert_allclose(out[k], g[k], atol=TOL, rtol=0, err_msg=f"{k} C={C} heads={heads} W={W}")
+
+
 def test_clip_box_and_hann_known_answers():
     import os
     from conftest import GOLDEN_DIR

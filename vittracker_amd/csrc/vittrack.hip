@@ -69,9 +69,10 @@ struct vt_model {
     VbModel* vb = nullptr;           // ViT-Base path (channels = 768): backbone + head towers live in vitb.hip
     // any other stride-16 geometry of the vit_48_h32 surface: the shape-generic kernels of vt_generic.h
     bool generic = false;
+    vtg::Dims gd{48, 1, 32};         // widths of the shape-generic path (round 6: any CHANNELS / HEADS / HEAD.NUM_CHANNELS)
     DevBuf g_stem_w[4], g_stem_b[4]; // folded conv weights [cout][cin][9] / bias
-    DevBuf g_blocks;                 // depth * vtg::GEN_BLOCK_STRIDE + 2 C (final norm)
-    DevBuf g_head;                   // 3 * vtg::GEN_TOWER_STRIDE
+    DevBuf g_blocks;                 // depth * gd.block_stride() + 2 C (final norm)
+    DevBuf g_head;                   // 3 * gd.tower_stride()
     DevBuf g_a, g_b;                 // stem ping-pong maps; then the head's
     DevBuf g_qkv, g_ao, g_hid, g_x;  // (B L, 3 C), (B L, C), (B L, 4 C); the residual stream being updated
     vt_config cfg{};
@@ -423,8 +424,9 @@ int gen_stem(vt_model* m, const float* z, const float* x, int B, hipStream_t st,
         const int T = side == 0 ? m->cfg.template_size : m->cfg.search_size;
         const float* in = img;
         int S = T;
+        const int C = m->gd.C, chans[5] = {3, C / 8, C / 4, C / 2, C};      // b16 (vit_dist.py:36-54)
         for (int i = 0; i < 4; ++i) {
-            const int cin = STEM_CH[i], cout = STEM_CH[i + 1], So = S / 2;
+            const int cin = chans[i], cout = chans[i + 1], So = S / 2;
             float* out = (i & 1) ? m->g_b.p : m->g_a.p;
             const size_t total = (size_t)B * cout * So * So;
             if (i == 0 && side == 1 && xu8) {      // the search crop arrives as sample_target's uint8 patch: Preprocessor.process per tap, same weights
@@ -451,35 +453,46 @@ int gen_blocks(vt_model* m, const float* tokens, int B, int nblocks, hipStream_t
     // the residual stream is updated in place in a buffer of its own: the caller's tokens -- and the cached template rows of
     // vt_set_template's token matrix -- stay untouched
     float* x = m->g_x.p;
-    HIP_TRY(hipMemcpyAsync(x, tokens, rows * 48 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const vtg::Dims d = m->gd;
+    const int C = d.C, HID = d.hid();
+    HIP_TRY(hipMemcpyAsync(x, tokens, rows * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < nblocks; ++i) {
-        const float* P = m->g_blocks.p + (size_t)i * vtg::GEN_BLOCK_STRIDE;
-        hipLaunchKernelGGL(vtg::ln_linear_kernel<0>, dim3(gen_grid(rows * 144)), dim3(256), 0, st, x, P + vtg::GO_WQKV, P + vtg::GO_BQKV, rows, 144, m->g_qkv.p);
-        hipLaunchKernelGGL(vtg::attn_kernel, dim3(gen_grid(rows)), dim3(256), 0, st, m->g_qkv.p, B, m->L, m->g_ao.p);
-        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * 48)), dim3(256), 0, st, m->g_ao.p, P + vtg::GO_WPROJ, P + vtg::GO_BPROJ, rows, 48, x);
-        hipLaunchKernelGGL(vtg::ln_linear_kernel<1>, dim3(gen_grid(rows * 192)), dim3(256), 0, st, x, P + vtg::GO_W1, P + vtg::GO_B1, rows, 192, m->g_hid.p);
-        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * 48)), dim3(256), 0, st, m->g_hid.p, P + vtg::GO_W2, P + vtg::GO_B2, rows, 192, x);
+        const float* P = m->g_blocks.p + (size_t)i * d.block_stride();
+        hipLaunchKernelGGL(vtg::ln_linear_kernel<0>, dim3(gen_grid(rows * 3 * C)), dim3(256), 0, st, x, P + d.o_wqkv(), P + d.o_bqkv(), rows, C, 3 * C, m->g_qkv.p);
+        const unsigned ag = gen_grid(rows * d.heads);
+        switch (d.hd()) {       // head_dim as a template value where it is a common one (registers), else the run-time form
+            case 16: hipLaunchKernelGGL(vtg::attn_kernel<16>, dim3(ag), dim3(256), 0, st, m->g_qkv.p, B, m->L, C, d.heads, m->g_ao.p); break;
+            case 32: hipLaunchKernelGGL(vtg::attn_kernel<32>, dim3(ag), dim3(256), 0, st, m->g_qkv.p, B, m->L, C, d.heads, m->g_ao.p); break;
+            case 48: hipLaunchKernelGGL(vtg::attn_kernel<48>, dim3(ag), dim3(256), 0, st, m->g_qkv.p, B, m->L, C, d.heads, m->g_ao.p); break;
+            case 64: hipLaunchKernelGGL(vtg::attn_kernel<64>, dim3(ag), dim3(256), 0, st, m->g_qkv.p, B, m->L, C, d.heads, m->g_ao.p); break;
+            default: hipLaunchKernelGGL(vtg::attn_kernel<0>, dim3(ag), dim3(256), 0, st, m->g_qkv.p, B, m->L, C, d.heads, m->g_ao.p); break;
+        }
+        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * C)), dim3(256), 0, st, m->g_ao.p, P + d.o_wproj(), P + d.o_bproj(), rows, C, C, x);
+        hipLaunchKernelGGL(vtg::ln_linear_kernel<1>, dim3(gen_grid(rows * HID)), dim3(256), 0, st, x, P + d.o_w1(), P + d.o_b1(), rows, C, HID, m->g_hid.p);
+        hipLaunchKernelGGL(vtg::linear_resid_kernel, dim3(gen_grid(rows * C)), dim3(256), 0, st, m->g_hid.p, P + d.o_w2(), P + d.o_b2(), rows, C, HID, x);
     }
-    if (resid) HIP_TRY(hipMemcpyAsync(resid, x, rows * 48 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    const float* N = m->g_blocks.p + (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE;
-    hipLaunchKernelGGL(vtg::final_norm_kernel, dim3(gen_grid((size_t)B * m->len_x * 48)), dim3(256), 0, st, x, N, N + 48, B, m->L, m->len_z, feat);
+    if (resid) HIP_TRY(hipMemcpyAsync(resid, x, rows * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const float* N = m->g_blocks.p + (size_t)m->cfg.depth * d.block_stride();
+    hipLaunchKernelGGL(vtg::final_norm_kernel, dim3(gen_grid((size_t)B * m->len_x * C)), dim3(256), 0, st, x, N, N + C, B, m->L, m->len_z, C, feat);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
 
 int gen_head(vt_model* m, const float* feat, int B, hipStream_t st, float* score, float* size, float* offset) {
     const int F = m->F;
+    const vtg::Dims d = m->gd;
     const size_t npx = (size_t)B * F * F;
     const float* in = feat;
     size_t in_stride = 0;
     for (int i = 0; i < 4; ++i) {
         float* out = (i & 1) ? m->g_b.p : m->g_a.p;
-        hipLaunchKernelGGL(vtg::head_conv_kernel, dim3(gen_grid(3 * npx * vtg::HCH[i + 1])), dim3(256), 0, st, in, in_stride, m->g_head.p, vtg::HO_W[i],
-                           vtg::HO_B[i], B, F, vtg::HCH[i], vtg::HCH[i + 1], out);
+        hipLaunchKernelGGL(vtg::head_conv_kernel, dim3(gen_grid(3 * npx * d.hch(i + 1))), dim3(256), 0, st, in, in_stride, m->g_head.p, d.tower_stride(),
+                           d.ho_w(i), d.ho_b(i), B, F, d.hch(i), d.hch(i + 1), out);
         in = out;
-        in_stride = npx * vtg::HCH[i + 1];
+        in_stride = npx * d.hch(i + 1);
     }
-    hipLaunchKernelGGL(vtg::head_out_kernel, dim3(gen_grid(npx)), dim3(256), 0, st, in, m->g_head.p, B, F, score, size, offset);
+    hipLaunchKernelGGL(vtg::head_out_kernel, dim3(gen_grid(npx)), dim3(256), 0, st, in, m->g_head.p, d.tower_stride(), d.ho_w5(), d.ho_b5(), d.hch(4), B, F,
+                       score, size, offset);
     HIP_TRY(hipGetLastError());
     return VT_OK;
 }
@@ -1130,6 +1143,90 @@ static hipError_t allow_stem_lds() {
     return e;
 }
 
+// vt_load_weights of the shape-generic path (vt_generic.h): plain row-major weights at run-time widths -- BatchNorm folded into the convs
+// (Conv2d_BN.fuse, vit_dist.py:22-33) and LayerNorm-1 / -2's affine part folded into qkv / fc1, both in fp64, as on the tuned path.
+static int load_weights_generic(vt_model* m, const TensorMap& tm) {
+    const vtg::Dims d = m->gd;
+    const int C = d.C, HID = d.hid();
+    int rc;
+    const int sch[5] = {3, C / 8, C / 4, C / 2, C};
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "patch_embed.net." + std::to_string(2 * i);
+        std::vector<double> w, b;
+        if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, sch[i + 1], sch[i], w, b))) return rc;
+        if ((rc = upload(m->g_stem_w[i], std::vector<float>(w.begin(), w.end())))) return rc;
+        if ((rc = upload(m->g_stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
+    }
+    const float* p;
+    if ((rc = need(tm, "pos_embed_z", (int64_t)m->len_z * C, &p))) return rc;
+    if ((rc = upload(m->pos_z, std::vector<float>(p, p + (size_t)m->len_z * C)))) return rc;
+    if ((rc = need(tm, "pos_embed_x", (int64_t)m->len_x * C, &p))) return rc;
+    if ((rc = upload(m->pos_x, std::vector<float>(p, p + (size_t)m->len_x * C)))) return rc;
+    std::vector<float> gbp((size_t)m->cfg.depth * d.block_stride() + 2 * C);
+    for (int b = 0; b < m->cfg.depth; ++b) {
+        const std::string pre = "blocks." + std::to_string(b) + ".";
+        float* g = gbp.data() + (size_t)b * d.block_stride();
+        // y = W (gamma * n + beta) + b = (W diag gamma) n + (b + W beta)
+        auto fold_ln = [&](const char* ln, const char* lin, int out, int o_w, int o_b) -> int {
+            const float *G, *Be, *W, *Bi;
+            int r2;
+            if ((r2 = need(tm, pre + ln + ".weight", C, &G)) || (r2 = need(tm, pre + ln + ".bias", C, &Be)) ||
+                (r2 = need(tm, pre + lin + ".weight", (int64_t)out * C, &W)) || (r2 = need(tm, pre + lin + ".bias", out, &Bi)))
+                return r2;
+            for (int o = 0; o < out; ++o) {
+                double acc = (double)Bi[o];
+                for (int i = 0; i < C; ++i) {
+                    g[o_w + (size_t)o * C + i] = (float)((double)W[(size_t)o * C + i] * (double)G[i]);
+                    acc += (double)W[(size_t)o * C + i] * (double)Be[i];
+                }
+                g[o_b + o] = (float)acc;
+            }
+            return VT_OK;
+        };
+        auto plain = [&](const char* lin, int out, int in, int o_w, int o_b) -> int {
+            const float *W, *Bi;
+            int r2;
+            if ((r2 = need(tm, pre + lin + ".weight", (int64_t)out * in, &W)) || (r2 = need(tm, pre + lin + ".bias", out, &Bi))) return r2;
+            std::memcpy(g + o_w, W, (size_t)out * in * sizeof(float));
+            std::memcpy(g + o_b, Bi, (size_t)out * sizeof(float));
+            return VT_OK;
+        };
+        if ((rc = fold_ln("norm1", "attn.qkv", 3 * C, d.o_wqkv(), d.o_bqkv()))) return rc;
+        if ((rc = plain("attn.proj", C, C, d.o_wproj(), d.o_bproj()))) return rc;
+        if ((rc = fold_ln("norm2", "mlp.fc1", HID, d.o_w1(), d.o_b1()))) return rc;
+        if ((rc = plain("mlp.fc2", C, HID, d.o_w2(), d.o_b2()))) return rc;
+    }
+    {
+        float* g = gbp.data() + (size_t)m->cfg.depth * d.block_stride();
+        if ((rc = need(tm, "norm.weight", C, &p))) return rc;
+        std::memcpy(g, p, C * sizeof(float));
+        if ((rc = need(tm, "norm.bias", C, &p))) return rc;
+        std::memcpy(g + C, p, C * sizeof(float));
+    }
+    if ((rc = upload(m->g_blocks, gbp))) return rc;
+    std::vector<float> ghp((size_t)3 * d.tower_stride(), 0.f);
+    const char* towers[3] = {"ctr", "offset", "size"};
+    for (int t = 0; t < 3; ++t) {
+        float* g = ghp.data() + (size_t)t * d.tower_stride();
+        for (int i = 0; i < 4; ++i) {
+            const std::string cn = std::string("box_head.conv") + std::to_string(i + 1) + "_" + towers[t];
+            std::vector<double> w, b;
+            if ((rc = fold_conv_bn(tm, cn + ".0", cn + ".1", true, d.hch(i + 1), d.hch(i), w, b))) return rc;
+            for (size_t k = 0; k < w.size(); ++k) g[d.ho_w(i) + k] = (float)w[k];
+            for (int o = 0; o < d.hch(i + 1); ++o) g[d.ho_b(i) + o] = (float)b[o];
+        }
+        const int nout = t == 0 ? 1 : 2, c4 = d.hch(4);
+        const std::string c5 = std::string("box_head.conv5_") + towers[t];
+        if ((rc = need(tm, c5 + ".weight", (int64_t)nout * c4, &p))) return rc;
+        std::memcpy(g + d.ho_w5(), p, (size_t)nout * c4 * sizeof(float));
+        if ((rc = need(tm, c5 + ".bias", nout, &p))) return rc;
+        std::memcpy(g + d.ho_b5(), p, nout * sizeof(float));
+    }
+    if ((rc = upload(m->g_head, ghp))) return rc;
+    m->weights_loaded = true;
+    return VT_OK;
+}
+
 extern "C" {
 
 const char* vt_last_error(void) { return g_err.c_str(); }
@@ -1138,13 +1235,18 @@ const char* vt_version(void) { return "vittrack-hip 0.2 (gfx950, " VT_PRECISION_
 int vt_create(const vt_config* cfg, vt_model** out) {
     if (!cfg || !out) return fail(VT_ERR_ARG, "null argument");
     if (cfg->channels == 768) return create_vitb(cfg, out);
-    if (cfg->channels != 48 || cfg->heads != 1 || cfg->head_channels != 32 || cfg->stride != 16)
+    // build_ostrack_dist takes embed_dim / num_heads / the head width from the YAML (vit_dist.py:159-164; head.py:352-359): the shipped widths
+    // (48, 1, 32) at the two geometries of the repository's configs run the tuned kernels, everything else the shape-generic ones
+    const bool shipped_widths = cfg->channels == 48 && cfg->heads == 1 && cfg->head_channels == 32;
+    if (cfg->stride != 16 || cfg->channels < 8 || cfg->channels > 1024 || cfg->channels % 8 != 0 || cfg->heads < 1 || cfg->channels % cfg->heads != 0 ||
+        cfg->channels / cfg->heads > vtg::MAXHD || cfg->head_channels < 8 || cfg->head_channels > 1024 || cfg->head_channels % 8 != 0)
         return fail(VT_ERR_ARG,
-                    "unsupported model: this build implements CHANNELS=48, HEADS=1, HEAD.NUM_CHANNELS=32, STRIDE=16 "
-                    "(the shipped vit_48_h32 config) and CHANNELS=768, HEADS=12, HEAD.NUM_CHANNELS=256 (ViT-Base OSTrack-256); got channels=" + std::to_string(cfg->channels) + " heads=" +
-                        std::to_string(cfg->heads) + " head_channels=" + std::to_string(cfg->head_channels));
-    const bool g128 = cfg->template_size == 64 && cfg->search_size == 128;
-    const bool g256 = cfg->template_size == 128 && cfg->search_size == 256;
+                    "unsupported model: STRIDE must be 16, CHANNELS a multiple of 8 (the stem's widths are C/8, C/4, C/2, C) divisible by HEADS with a head "
+                    "dimension of at most " + std::to_string(vtg::MAXHD) + ", HEAD.NUM_CHANNELS a multiple of 8 (the towers' widths are W, W/2, W/4, W/8); "
+                    "got channels=" + std::to_string(cfg->channels) + " heads=" + std::to_string(cfg->heads) + " head_channels=" + std::to_string(cfg->head_channels) +
+                    " stride=" + std::to_string(cfg->stride));
+    const bool g128 = shipped_widths && cfg->template_size == 64 && cfg->search_size == 128;
+    const bool g256 = shipped_widths && cfg->template_size == 128 && cfg->search_size == 256;
     const bool generic = !g128 && !g256;
     if (generic && (cfg->template_size % 16 != 0 || cfg->search_size % 16 != 0 || cfg->template_size < 16 || cfg->search_size < 16 ||
                     cfg->template_size > 512 || cfg->search_size > 512))
@@ -1171,18 +1273,20 @@ int vt_create(const vt_config* cfg, vt_model** out) {
     int rc = VT_OK;
     auto A = [&](DevBuf& d, size_t n) { if (!rc) rc = d.alloc(n); };
     m->generic = generic;
-    A(m->tokens, B * m->L * 48);
-    A(m->feat, B * m->len_x * 48);
-    A(m->tokens_c, B * m->L * 48);
+    m->gd = vtg::Dims{cfg->channels, cfg->heads, cfg->head_channels};
+    const size_t C = (size_t)cfg->channels, HW = (size_t)cfg->head_channels;
+    A(m->tokens, B * m->L * C);
+    A(m->feat, B * m->len_x * C);
+    A(m->tokens_c, B * m->L * C);
     if (generic) {
         const size_t T = (size_t)std::max(cfg->search_size, cfg->template_size);
         // ping-pong maps: stem layers 1 / 3 and head convs 1 / 3 in g_a, layers 2 and convs 2 / 4 in g_b
-        A(m->g_a, std::max(B * 6 * (T / 2) * (T / 2), 3 * B * (size_t)m->len_x * 32));
-        A(m->g_b, std::max(B * 12 * (T / 4) * (T / 4), 3 * B * (size_t)m->len_x * 16));
-        A(m->g_qkv, B * m->L * 144);
-        A(m->g_ao, B * m->L * 48);
-        A(m->g_hid, B * m->L * 192);
-        A(m->g_x, B * m->L * 48);
+        A(m->g_a, std::max({B * (C / 8) * (T / 2) * (T / 2), B * (C / 2) * (T / 8) * (T / 8), 3 * B * (size_t)m->len_x * HW}));
+        A(m->g_b, std::max(B * (C / 4) * (T / 4) * (T / 4), 3 * B * (size_t)m->len_x * (HW / 2)));
+        A(m->g_qkv, B * m->L * 3 * C);
+        A(m->g_ao, B * m->L * C);
+        A(m->g_hid, B * m->L * 4 * C);
+        A(m->g_x, B * m->L * C);
     } else {
     A(m->act_x, B * (size_t)(cfg->search_size / 4) * (cfg->search_size / 4) * 12);
     A(m->act_z, B * (size_t)(cfg->template_size / 4) * (cfg->template_size / 4) * 12);
@@ -1387,17 +1491,13 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         m->weights_loaded = true;
         return VT_OK;
     }
+    if (m->generic) return load_weights_generic(m, tm);
     const int C = 48;
     // ---- stem (patch_embed.net.{0,2,4,6}.{c,bn})
     for (int i = 0; i < 4; ++i) {
         const std::string p = "patch_embed.net." + std::to_string(2 * i);
         std::vector<double> w, b;
         if ((rc = fold_conv_bn(tm, p + ".c", p + ".bn", false, STEM_CH[i + 1], STEM_CH[i], w, b))) return rc;
-        if (m->generic) {      // plain [cout][cin][9] weights for vt_generic.h; none of the tuned kernels' images
-            if ((rc = upload(m->g_stem_w[i], std::vector<float>(w.begin(), w.end())))) return rc;
-            if ((rc = upload(m->g_stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
-            continue;
-        }
         if (i < 1) {   // VALU layer: [r][cin][s][cout] sections, weights become scalar operands
             if ((rc = upload(m->stem_w[i], pack_conv_sections(w, STEM_CH[i + 1], STEM_CH[i])))) return rc;
             if ((rc = upload(m->stem_b[i], std::vector<float>(b.begin(), b.end())))) return rc;
@@ -1446,7 +1546,6 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
     // ---- transformer blocks + final norm
     std::vector<float> bp((size_t)m->cfg.depth * vtb::BLOCK_STRIDE + 2 * C);
     std::vector<uint16_t> bp3((size_t)m->cfg.depth * vtb::BLOCK3_STRIDE * 2, 0);
-    std::vector<float> gbp(m->generic ? (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE + 2 * C : 0);      // vt_generic.h: plain [out][in] weights
     for (int b = 0; b < m->cfg.depth; ++b) {
         const std::string pre = "blocks." + std::to_string(b) + ".";
         float* dst = bp.data() + (size_t)b * vtb::BLOCK_STRIDE;
@@ -1461,8 +1560,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         }
         // norm1 -> qkv and norm2 -> fc1: the LayerNorm's affine part is folded into the linear layer that consumes it, in
         // double (y = W (gamma * n + beta) + b = (W diag gamma) n + (b + W beta)); the kernels normalise only (vt_blocks.h).
-        float* gdst = m->generic ? gbp.data() + (size_t)b * vtg::GEN_BLOCK_STRIDE : nullptr;
-        auto fold_ln = [&](const char* wname, int out, int o_ln_g, int o_ln_b, int o_bias, int o_w, int go_w, int go_b) -> int {
+        auto fold_ln = [&](const char* wname, int out, int o_ln_g, int o_ln_b, int o_bias, int o_w) -> int {
             const float* W;
             int rc2 = need(tm, pre + wname, (int64_t)out * C, &W);
             if (rc2) return rc2;
@@ -1476,20 +1574,14 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
                 dst[o_bias + o] = (float)acc;
             }
             pack_linear_image(wf.data(), out, C, dst + o_w);
-            if (gdst) {
-                std::memcpy(gdst + go_w, wf.data(), wf.size() * sizeof(float));
-                std::memcpy(gdst + go_b, dst + o_bias, out * sizeof(float));
-            }
             return VT_OK;
         };
-        if ((rc = fold_ln("attn.qkv.weight", 3 * C, vtb::O_LN1G, vtb::O_LN1B, vtb::O_BQKV, vtb::O_WQKV, vtg::GO_WQKV, vtg::GO_BQKV))) return rc;
+        if ((rc = fold_ln("attn.qkv.weight", 3 * C, vtb::O_LN1G, vtb::O_LN1B, vtb::O_BQKV, vtb::O_WQKV))) return rc;
         if ((rc = need(tm, pre + "attn.proj.weight", C * C, &p))) return rc;
         pack_linear_image(p, C, C, dst + vtb::O_WPROJ);
-        if (gdst) { std::memcpy(gdst + vtg::GO_WPROJ, p, (size_t)C * C * sizeof(float)); std::memcpy(gdst + vtg::GO_BPROJ, dst + vtb::O_BPROJ, C * sizeof(float)); }
-        if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1, vtg::GO_W1, vtg::GO_B1))) return rc;
+        if ((rc = fold_ln("mlp.fc1.weight", 4 * C, vtb::O_LN2G, vtb::O_LN2B, vtb::O_B1, vtb::O_W1))) return rc;
         if ((rc = need(tm, pre + "mlp.fc2.weight", 4 * C * C, &p))) return rc;
         pack_linear_image(p, C, 4 * C, dst + vtb::O_W2);
-        if (gdst) { std::memcpy(gdst + vtg::GO_W2, p, (size_t)4 * C * C * sizeof(float)); std::memcpy(gdst + vtg::GO_B2, dst + vtb::O_B2, C * sizeof(float)); }
         pack_mlp_images3(dst + vtb::O_W1, dst + vtb::O_W2, dst + vtb::O_WQKV, dst + vtb::O_WPROJ, bp3.data() + (size_t)b * vtb::BLOCK3_STRIDE * 2);
     }
     {
@@ -1498,10 +1590,6 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst, p, C * sizeof(float));
         if ((rc = need(tm, "norm.bias", C, &p))) return rc;
         std::memcpy(dst + C, p, C * sizeof(float));
-    }
-    if (m->generic) {
-        std::memcpy(gbp.data() + (size_t)m->cfg.depth * vtg::GEN_BLOCK_STRIDE, bp.data() + (size_t)m->cfg.depth * vtb::BLOCK_STRIDE, 2 * C * sizeof(float));
-        if ((rc = upload(m->g_blocks, gbp))) return rc;
     }
     if ((rc = upload(m->blocks, bp))) return rc;
 #ifdef VT_F16
@@ -1525,7 +1613,6 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
 #endif
     // ---- head (box_head.conv{1..4}_{ctr,offset,size}.{0,1}, conv5_*)
     std::vector<float> hp((size_t)3 * vth::TOWER_STRIDE, 0.f);
-    std::vector<float> ghp(m->generic ? (size_t)3 * vtg::GEN_TOWER_STRIDE : 0, 0.f);
 #ifndef VT_F16
     std::vector<uint16_t> hp3((size_t)3 * vth3::TOWER3_STRIDE * 8, 0);
 #endif
@@ -1549,11 +1636,6 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
             }
 #endif
             for (int o = 0; o < chans[i + 1]; ++o) dst[boff[i] + o] = (float)b[o];
-            if (m->generic) {
-                float* g = ghp.data() + (size_t)t * vtg::GEN_TOWER_STRIDE;
-                for (size_t k = 0; k < w.size(); ++k) g[vtg::HO_W[i] + k] = (float)w[k];
-                for (int o = 0; o < chans[i + 1]; ++o) g[vtg::HO_B[i] + o] = (float)b[o];
-            }
         }
         const int nout = t == 0 ? 1 : 2;
         const std::string c5 = std::string("box_head.conv5_") + towers[t];
@@ -1561,13 +1643,7 @@ int vt_load_weights(vt_model* m, const vt_tensor* tensors, int32_t n) {
         std::memcpy(dst + vth::O_W5, p, nout * 4 * sizeof(float));
         if ((rc = need(tm, c5 + ".bias", nout, &p))) return rc;
         std::memcpy(dst + vth::O_B5, p, nout * sizeof(float));
-        if (m->generic) {
-            float* g = ghp.data() + (size_t)t * vtg::GEN_TOWER_STRIDE;
-            std::memcpy(g + vtg::HO_W5, dst + vth::O_W5, nout * 4 * sizeof(float));
-            std::memcpy(g + vtg::HO_B5, dst + vth::O_B5, nout * sizeof(float));
-        }
     }
-    if (m->generic && (rc = upload(m->g_head, ghp))) return rc;
     if ((rc = upload(m->head, hp))) return rc;
 #ifdef VT_F16
     for (int t = 0; t < 3; ++t)      // the towers' conv images as stored operands, in place (biases and conv5 stay float)

@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 5 && !WLDS) ? 3 : 1) void blocks_ke
             u32x2 pl[3];            // pieces of the pair's first tile
             f2 ua, ub, na, nb, pa, pb, ea, eb;      // GELU state between stages (pairs (x, y) and (z, w) of `prev`)
             unsigned xb[4], r1b[4], r2b[4];
-            u32x2 hpk, mpk;      // VT_SPLIT_DOT2: the packed h / m pieces, which the residuals are computed from (vt_bf3.h)
+            [[maybe_unused]] u32x2 hpk, mpk;      // VT_SPLIT_DOT2: the packed h / m pieces, which the residuals are computed from (vt_bf3.h)
             auto gstage = [&](int e) {
                 const auto fma2 = [](f2 p, f2 n, float c) { return __builtin_elementwise_fma(p, n, f2{c, c}); };
                 if (e == 0) {

@@ -1,4 +1,4 @@
-// vt_generic.h -- the vit_dist forward for ANY stride-16 (template, search) geometry of the vit_48_h32 config surface.
+// vt_generic.h -- the vit_dist forward for ANY stride-16 (template, search) geometry and (round 6) ANY widths of the vit_dist config surface.
 //
 // build_ostrack_dist (lib/models/vit_dist/vit_dist.py:159-198) builds the model from whatever DATA.TEMPLATE.SIZE / DATA.SEARCH.SIZE
 // the YAML names (lib/utils/ce_utils.py:22-32 lists template feature sizes 8 / 12 / 7 / 14); the tuned kernels of this library are
@@ -20,27 +20,35 @@
 
 namespace vtg {
 
-constexpr int C = 48, HID = 192;
 constexpr float LN_EPS = 1e-5f;
 
-// per-block parameter offsets (floats) of the generic parameter buffer: plain row-major nn.Linear weights [out][in], LayerNorm folded
-constexpr int GO_WQKV = 0;
-constexpr int GO_BQKV = GO_WQKV + 3 * C * C;
-constexpr int GO_WPROJ = GO_BQKV + 3 * C;
-constexpr int GO_BPROJ = GO_WPROJ + C * C;
-constexpr int GO_W1 = GO_BPROJ + C;
-constexpr int GO_B1 = GO_W1 + HID * C;
-constexpr int GO_W2 = GO_B1 + HID;
-constexpr int GO_B2 = GO_W2 + C * HID;
-constexpr int GEN_BLOCK_STRIDE = GO_B2 + C;          // the final norm's gamma, beta (2 C) follow the last block
-
-// per-tower head parameters: conv i as [cout][cin][9] (BN folded) + bias, conv5 [<= 2][4] + bias
-constexpr int HCH[5] = {48, 32, 16, 8, 4};
-constexpr int HO_W[4] = {0, 13856, 18480, 19640};     // conv weights
-constexpr int HO_B[4] = {13824, 18464, 19632, 19928}; // conv biases
-constexpr int HO_W5 = 19932, HO_B5 = 19940, GEN_TOWER_STRIDE = 19944;
-static_assert(HO_B[0] == HO_W[0] + 32 * 48 * 9 && HO_W[1] == HO_B[0] + 32 && HO_B[1] == HO_W[1] + 16 * 32 * 9 && HO_W[2] == HO_B[1] + 16 &&
-              HO_B[2] == HO_W[2] + 8 * 16 * 9 && HO_W[3] == HO_B[2] + 8 && HO_B[3] == HO_W[3] + 4 * 8 * 9 && HO_W5 == HO_B[3] + 4, "tower layout");
+// Round 6: the widths are run-time values too -- build_ostrack_dist takes embed_dim = MODEL.BACKBONE.CHANNELS, num_heads = MODEL.BACKBONE.HEADS
+// and the head's MODEL.HEAD.NUM_CHANNELS from the YAML (lib/models/vit_dist/vit_dist.py:159-164; lib/models/layers/head.py:352-359), and
+// every combination other than the shipped (48, 1, 32) runs here, at any stride-16 geometry.
+struct Dims {
+    int C;        // embed_dim: stem channels C/8, C/4, C/2, C (vit_dist.py:36-54: b16); MLP hidden 4 C
+    int heads;    // attention heads, head_dim = C / heads
+    int W;        // head tower widths W, W/2, W/4, W/8 (head.py:104-128)
+    __host__ __device__ int hid() const { return 4 * C; }
+    __host__ __device__ int hd() const { return C / heads; }
+    // per-block parameter offsets (floats): plain row-major nn.Linear weights [out][in], LayerNorm folded
+    __host__ __device__ int o_wqkv() const { return 0; }
+    __host__ __device__ int o_bqkv() const { return 3 * C * C; }
+    __host__ __device__ int o_wproj() const { return o_bqkv() + 3 * C; }
+    __host__ __device__ int o_bproj() const { return o_wproj() + C * C; }
+    __host__ __device__ int o_w1() const { return o_bproj() + C; }
+    __host__ __device__ int o_b1() const { return o_w1() + 4 * C * C; }
+    __host__ __device__ int o_w2() const { return o_b1() + 4 * C; }
+    __host__ __device__ int o_b2() const { return o_w2() + 4 * C * C; }
+    __host__ __device__ int block_stride() const { return o_b2() + C; }          // the final norm's gamma, beta (2 C) follow the last block
+    // per-tower head parameters: conv i as [cout][cin][9] (BN folded) + bias, conv5 [<= 2][W / 8] + bias
+    __host__ __device__ int hch(int i) const { return i == 0 ? C : W >> (i - 1); }
+    __host__ __device__ int ho_w(int i) const { int o = 0; for (int k = 0; k < i; ++k) o += hch(k + 1) * hch(k) * 9 + hch(k + 1); return o; }
+    __host__ __device__ int ho_b(int i) const { return ho_w(i) + hch(i + 1) * hch(i) * 9; }
+    __host__ __device__ int ho_w5() const { return ho_w(4); }
+    __host__ __device__ int ho_b5() const { return ho_w5() + 2 * hch(4); }
+    __host__ __device__ int tower_stride() const { return ho_b5() + 4; }
+};
 
 __device__ __forceinline__ float hardswish(float v) { return v * fminf(fmaxf(v + 3.0f, 0.0f), 6.0f) / 6.0f; }
 __device__ __forceinline__ float gelu_erf(float u) { return u * 0.5f * (1.0f + erff(u * 0.70710678118654752f)); }
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             }
         }
     }
-    if (tokens) tokens[((size_t)b * L + row0 + oy * So + ox) * C + oc] = acc + pos[((size_t)oy * So + ox) * C + oc];
+    if (tokens) tokens[((size_t)b * L + row0 + oy * So + ox) * Cout + oc] = acc + pos[((size_t)oy * So + ox) * Cout + oc];      // the last layer: Cout = embed_dim
     else out[idx] = hardswish(acc);
 }
 
@@ -129,61 +137,62 @@ __global__ __launch_bounds__(256) void stem_conv_u8_kernel(const unsigned char* 
 }
 
 // out[row][o] = act(LN_plain(x[row]) . W[o] + bias[o]); the LayerNorm's affine part is folded into W / bias.  ACT: 0 none, 1 GELU(erf)
+// (the row is read three times -- mean, variance, product -- from L1: no per-thread array of run-time length)
 template <int ACT>
 __global__ __launch_bounds__(256) void ln_linear_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                                        size_t rows, int OUT, float* __restrict__ out) {
+                                                        size_t rows, int C, int OUT, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * OUT) return;
     const size_t row = idx / OUT;
     const int o = (int)(idx - row * OUT);
     const float* xr = x + row * C;
-    float v[C], mean = 0.f;
-#pragma unroll
-    for (int i = 0; i < C; ++i) { v[i] = xr[i]; mean += v[i]; }
+    float mean = 0.f;
+    for (int i = 0; i < C; ++i) mean += xr[i];
     mean *= 1.0f / C;
     float var = 0.f;
-#pragma unroll
-    for (int i = 0; i < C; ++i) { v[i] -= mean; var = fmaf(v[i], v[i], var); }
+    for (int i = 0; i < C; ++i) { const float d = xr[i] - mean; var = fmaf(d, d, var); }
     const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
     float acc = 0.f;
     const float* wr = W + (size_t)o * C;
-#pragma unroll
-    for (int i = 0; i < C; ++i) acc = fmaf(v[i], wr[i], acc);
+    for (int i = 0; i < C; ++i) acc = fmaf(xr[i] - mean, wr[i], acc);
     acc = fmaf(acc, rstd, bias[o]);
     out[idx] = ACT == 1 ? gelu_erf(acc) : acc;
 }
 
-// one thread per query: softmax((q . k_j) * C^-0.5) over ALL L keys of the frame, online.  qkv rows = [q | k | v] (3 C floats)
-__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int B, int L, float* __restrict__ out) {
+// one thread per (query, head): softmax((q . k_j) * head_dim^-0.5) over ALL L keys of the frame, online (attn.py:33-59).  qkv rows =
+// [q | k | v] (3 C floats), head h = columns h HD .. of each.  HD = head_dim as a template value (registers); HD = 0: any head_dim
+// up to MAXHD through local arrays.
+constexpr int MAXHD = 256;
+template <int HDT>
+__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int B, int L, int C, int heads, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)B * L) return;
-    const int b = (int)(idx / L);
-    const float scale = 0.14433756729740643f;       // 48^-0.5 (head_dim ** -0.5, attn.py:15)
-    float q[C], o[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) { q[i] = qkv[idx * 3 * C + i]; o[i] = 0.f; }
+    if (idx >= (size_t)B * L * heads) return;
+    const int h = (int)(idx % heads);
+    const size_t tokrow = idx / heads;                 // b L + query
+    const int b = (int)(tokrow / L);
+    const int HD = HDT > 0 ? HDT : C / heads;
+    const float scale = 1.0f / sqrtf((float)HD);       // head_dim ** -0.5 (attn.py:15)
+    float q[HDT > 0 ? HDT : MAXHD], o[HDT > 0 ? HDT : MAXHD];
+    for (int i = 0; i < HD; ++i) { q[i] = qkv[tokrow * 3 * C + h * HD + i]; o[i] = 0.f; }
     float m = -3.0e38f, l = 0.f;
-    const float* kv = qkv + (size_t)b * L * 3 * C;
+    const float* kv = qkv + (size_t)b * L * 3 * C + h * HD;
     for (int j = 0; j < L; ++j) {
         const float* kj = kv + (size_t)j * 3 * C + C;
         float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < C; ++i) s = fmaf(q[i], kj[i], s);
+        for (int i = 0; i < HD; ++i) s = fmaf(q[i], kj[i], s);
         s *= scale;
         const float mn = fmaxf(m, s), corr = expf(m - mn), p = expf(s - mn);
         l = fmaf(l, corr, p);
-#pragma unroll
-        for (int i = 0; i < C; ++i) o[i] = fmaf(o[i], corr, p * kj[C + i]);
+        for (int i = 0; i < HD; ++i) o[i] = fmaf(o[i], corr, p * kj[C + i]);
         m = mn;
     }
     const float rl = 1.0f / l;
-#pragma unroll
-    for (int i = 0; i < C; ++i) out[idx * C + i] = o[i] * rl;
+    for (int i = 0; i < HD; ++i) out[tokrow * C + h * HD + i] = o[i] * rl;
 }
 
 // x[row][o] += in[row] . W[o] + bias[o]   (proj: K = C; fc2: K = 4 C)
 __global__ __launch_bounds__(256) void linear_resid_kernel(const float* __restrict__ in, const float* __restrict__ W, const float* __restrict__ bias,
-                                                           size_t rows, int K, float* __restrict__ x) {
+                                                           size_t rows, int C, int K, float* __restrict__ x) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * C) return;
     const size_t row = idx / C;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256) void linear_resid_kernel(const float* __restri
 
 // feat[(b Lx + t)][c] = LayerNorm(x[b L + len_z + t]) (affine): the search rows only (vit_dist.py:94,126)
 __global__ __launch_bounds__(256) void final_norm_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ be,
-                                                         int B, int L, int len_z, float* __restrict__ feat) {
+                                                         int B, int L, int len_z, int C, float* __restrict__ feat) {
     const int Lx = L - len_z;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)B * Lx * C) return;
@@ -206,20 +215,19 @@ __global__ __launch_bounds__(256) void final_norm_kernel(const float* __restrict
     const int t = (int)(r % Lx), b = (int)(r / Lx);
     const float* xr = x + ((size_t)b * L + len_z + t) * C;
     float mean = 0.f;
-#pragma unroll
     for (int i = 0; i < C; ++i) mean += xr[i];
     mean *= 1.0f / C;
     float var = 0.f;
-#pragma unroll
     for (int i = 0; i < C; ++i) { const float d = xr[i] - mean; var = fmaf(d, d, var); }
     const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
     feat[idx] = (xr[c] - mean) * rstd * g[c] + be[c];
 }
 
 // conv3x3 stride 1 pad 1 + folded BN + ReLU over pixel-major maps: in [tower][B][F F][Cin] (in_tower_stride = 0: one shared input, the
-// normalised search tokens), out [tower][B][F F][Cout]; hw = the towers' parameter blocks (GEN_TOWER_STRIDE apart)
+// normalised search tokens), out [tower][B][F F][Cout]; hw = the towers' parameter blocks (tower_stride apart)
 __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ in, size_t in_tower_stride, const float* __restrict__ hw,
-                                                        int w_off, int b_off, int B, int F, int Cin, int Cout, float* __restrict__ out) {
+                                                        int tower_stride, int w_off, int b_off, int B, int F, int Cin, int Cout,
+                                                        float* __restrict__ out) {
     const size_t per_tower = (size_t)B * F * F * Cout;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= 3 * per_tower) return;
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     const int oc = (int)(r % Cout); r /= Cout;
     const int pix = (int)(r % ((size_t)F * F)), b = (int)(r / ((size_t)F * F));
     const int y = pix / F, x = pix - y * F;
-    const float* P = hw + (size_t)t * GEN_TOWER_STRIDE;
+    const float* P = hw + (size_t)t * tower_stride;
     const float* src = in + (size_t)t * in_tower_stride + (size_t)b * F * F * Cin;
     float acc = P[b_off + oc];
 #pragma unroll
@@ -247,24 +255,24 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     out[idx] = fmaxf(acc, 0.f);
 }
 
-// conv5 (1x1) of the three towers + sigmoid / clamp on ctr and size (head.py:175-201).  t4: [tower][B][F F][4]
-__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ t4, const float* __restrict__ hw, int B, int F,
-                                                       float* __restrict__ score, float* __restrict__ size, float* __restrict__ offset) {
+// conv5 (1x1) of the three towers + sigmoid / clamp on ctr and size (head.py:175-201).  t4: [tower][B][F F][C4], C4 = W / 8
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ t4, const float* __restrict__ hw, int tower_stride, int o_w5,
+                                                       int o_b5, int C4, int B, int F, float* __restrict__ score, float* __restrict__ size,
+                                                       float* __restrict__ offset) {
     const int n = F * F;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)B * n) return;
     const int b = (int)(idx / n), pix = (int)(idx - (size_t)b * n);
-    const size_t per_tower = (size_t)B * n * 4;
+    const size_t per_tower = (size_t)B * n * C4;
     float o[5];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-        const float* P = hw + (size_t)t * GEN_TOWER_STRIDE;
-        const float* v = t4 + (size_t)t * per_tower + idx * 4;
+        const float* P = hw + (size_t)t * tower_stride;
+        const float* v = t4 + (size_t)t * per_tower + idx * C4;
         const int nout = t == 0 ? 1 : 2, o0 = t == 0 ? 0 : (t == 1 ? 1 : 3);
         for (int k = 0; k < nout; ++k) {
-            float acc = P[HO_B5 + k];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc = fmaf(v[c], P[HO_W5 + k * 4 + c], acc);
+            float acc = P[o_b5 + k];
+            for (int c = 0; c < C4; ++c) acc = fmaf(v[c], P[o_w5 + k * C4 + c], acc);
             o[o0 + k] = acc;
         }
     }
