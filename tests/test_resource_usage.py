@@ -39,7 +39,10 @@ DEFAULT_VIT48 = [
 ]
 # vts::stem_a2_kernel reports ScratchSize 36 with VGPRs Spill 0 and not one scratch instruction: SGPRs spilled to VGPR lanes reserve a
 # frame that is never touched.  It must stay free of VGPR spills.
-SGPR_FRAME_ONLY = [r"vts::stem_a2_kernel"]
+SGPR_FRAME_ONLY = [r"vts::stem_a2_kernel",
+                   # the shape-generic attention at a head dimension that is none of 16 / 32 / 48 / 64: its q / o arrays of run-time length
+                   # live in scratch BY DESIGN (vt_generic.h: reference-implementation speed); no register is spilled
+                   r"vtg::attn_kernel<0>"]
 # The G256 block kernel with K as pieces (VT_BLOCKS_BF3=2, the default; round 5) parks the q of a wave's second and third token tile
 # (6 float4) and one residual chunk in scratch across the qkv barrier and reloads each once where that tile's attention starts --
 # seven 16-byte stores + loads per block and wave, outside every loop (the 20-tile form holds three tiles' residual streams and q
