@@ -2,7 +2,7 @@
 """End-to-end lock-step tracking of B synthetic sequences (frames uploaded from the host every step):
 the real-pipeline number next to bench.py's device-step number.
 
-    python tracking/track_batch_demo.py --batch 256 --frames 50 --size 480 640
+    python tracking/track_batch_demo.py --batch 256 --frames 240 --size 480 640
 """
 import argparse
 import os
@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--geom", default="", choices=["", "G128", "G256"],
                     help="shorthand for --config: G128 = vit_48_h32_g128 (128 / 64 px, BASELINE's metric), G256 = vit_48_h32_noKD (the shipped YAML)")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
     ap.add_argument("--hold-boxes", action="store_true",
                     help="reset every sequence's box to its initial one before each step (an 8 KB device copy per step inside the timed loops): on "
