@@ -484,7 +484,16 @@ __global__ __launch_bounds__(256) void crop_band_kernel(const unsigned char* __r
     typedef unsigned u3v __attribute__((ext_vector_type(3)));
     // a window can cross the end of the buffer only in the batch's last frame (its last rows): there every load takes the byte-aligned,
     // shifted-back form.  The two forms are two instantiations of one body (AL: aligned 12-byte loads), so neither holds the other's registers.
-    const bool last = b == (int)gridDim.y - 1;
+    // ... and there only in a band that reads the frame's last source row (its windows end at most 11 + 3 bytes past their first byte: inside
+    // the next row): every other band of the last frame takes the aligned form too -- the shifted form waits for each pair of windows before it
+    // requests the next (the shift is part of the request), a chain of 4 IPT memory round trips that the whole launch waited for
+    bool last = b == (int)gridDim.y - 1;
+    if (ALIGNED && last) {
+        int sl0, sl1, al0, al1;
+        lin_coeff(row0 + NROWS - 1, crop_sz, scale, sl0, sl1, al0, al1);
+        const int ymax = y1 + sl1 < vy1 - 1 ? y1 + sl1 : vy1 - 1;       // rows beyond the valid range read row 0
+        if (ymax <= H - 2 && W * 3 >= 16) last = false;
+    }
     unsigned two = 2u;
     asm volatile("" : "+v"(two));      // put_byte_shr2's shift operand has to live in a vector register
     const bool col_live = (wp[0] | wp[1] | wp[2] | wp[3]) != 0u;
@@ -494,8 +503,7 @@ __global__ __launch_bounds__(256) void crop_band_kernel(const unsigned char* __r
         u3v ra0[AL ? IPT : 1][4], ra1[AL ? IPT : 1][4];      // AL: the 12 aligned bytes around each window ...
         unsigned ro0[IPT], ro1[IPT];                          // ... and the item's row offsets: a window's shift is 8 x its offset's low two bits
         unsigned byw0[IPT], byw1[IPT];
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
+        auto issue = [&](int j) {
             const u4v e = *reinterpret_cast<const u4v*>(ytab + 4 * (j * RPG + rl));
             byw0[j] = e.z; byw1[j] = e.w; ro0[j] = e.x; ro1[j] = e.y;
             // an item whose two rows or whose four columns all lie in the crop's zero padding (a window reaching over the frame's
@@ -527,14 +535,8 @@ __global__ __launch_bounds__(256) void crop_band_kernel(const unsigned char* __r
                     }
                 }
             }
-        }
-        if ((VT_CROPF_DBG & 16) != 0) {
-            stamp(3);                                   // every load issued
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp(4);                                   // every window here
-        }
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
+        };
+        auto math = [&](int j) {
             const int oy = row0 + j * RPG + rl;
             float res[3][4];
             unsigned pk[3] = {0u, 0u, 0u};      // U8OUT: the 12 bytes of the item's four pixels, HWC
@@ -574,6 +576,22 @@ __global__ __launch_bounds__(256) void crop_band_kernel(const unsigned char* __r
 #pragma unroll
                 for (int c = 0; c < 3; ++c) st4(out + (((size_t)b * 3 + c) * T + oy) * T + 4 * cg, f4{res[c][0], res[c][1], res[c][2], res[c][3]});
             }
+        };
+        // two items at a time (the conditional loads are waited for as a whole anyway): half the window registers, so that the kernel
+        // stays within 128 registers = four workgroups per CU = ONE round of the 1024 bands of 256 G128 frames
+        constexpr int HS = IPT < 2 ? IPT : 2;
+#pragma unroll
+        for (int h = 0; h < IPT; h += HS) {
+#pragma unroll
+            for (int j = 0; j < HS; ++j) issue(h + j);
+            if ((VT_CROPF_DBG & 16) != 0 && h == 0) {
+                stamp(3);                                   // the first half's loads issued
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                stamp(4);                                   // ... and here
+            }
+#pragma unroll
+            for (int j = 0; j < HS; ++j) math(h + j);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     if (ALIGNED && !last) body(std::integral_constant<bool, ALIGNED>{});
