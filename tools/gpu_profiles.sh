@@ -14,11 +14,11 @@ for g in G128 G256; do
   gl=$(echo $g | tr A-Z a-z)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$g -- python3 $R/bench.py --geom $g --steps 100 --warmup 20 --no-cpu --no-extra --streams 1 > $O/stats_$g.log 2>&1
   cp $O/stats_$g/*/*kernel_stats.csv $O/r${N}_${gl}_kernel_stats.csv
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track_$g -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 40 --one-stream > $O/track_$g.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/track_$g -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 120 --one-stream --device-frames-only --hold-boxes > $O/track_$g.log 2>&1
   cp $O/track_$g/*/*kernel_stats.csv $O/r${N}_trackstep_${gl}_kernel_stats.csv
   # HBM bytes per launch of the tracker step's kernels (FETCH_SIZE / WRITE_SIZE, one pass each; held boxes: the 120-360 px windows of a tracker that follows a target)
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/trackpmc_${g}_$c -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 24 --one-stream --hold-boxes > $O/trackpmc_${g}_$c.log 2>&1
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/trackpmc_${g}_$c -- python3 $R/tracking/track_batch_demo.py --batch 256 --geom $g --frames 24 --one-stream --device-frames-only --hold-boxes > $O/trackpmc_${g}_$c.log 2>&1
   done
   python3 - $O $g $N <<'P'
 import csv, glob, sys, collections, json

@@ -29,6 +29,9 @@ def main():
                          "frame at G256 -- and the crop then reads a 40 px or a 2200 px window; held boxes keep the 120-360 px windows of a tracker "
                          "that follows a target")
     ap.add_argument("--one-stream", action="store_true", help="stop before the two-shard phase (profiling: per-kernel times of ONE step in flight)")
+    ap.add_argument("--device-frames-only", action="store_true",
+                    help="skip the host-frames phase (profiling: while the step waits 4 ms for each upload the GPU idles at low clocks, and that phase's "
+                         "kernels -- a fifth of a short run's -- read 1.3-1.5 x their busy-chip duration in a kernel trace)")
     a = ap.parse_args()
     if a.geom:
         a.config = {"G128": "vit_48_h32_g128", "G256": "vit_48_h32_noKD"}[a.geom]
@@ -47,17 +50,18 @@ def main():
     bt.initialize(frames[0], boxes)
     if a.hold_boxes:
         bt.hold_states(True)
-    for f in range(3):
-        bt.track(frames[f & 1], sync=False)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for f in range(a.frames):
-        out = bt.track(frames[f & 1], sync=False)
-    torch.cuda.synchronize()
-    dt = time.time() - t0
-    print(f"{B} sequences x {a.frames} frames of {H}x{W}: {B * a.frames / dt:.0f} frames/s end to end "
-          f"(host frames -> H2D -> crop -> graph -> state update), {dt / a.frames * 1e3:.2f} ms per step; "
-          f"H2D {B * H * W * 3 / 1e6:.0f} MB per step")
+    if not a.device_frames_only:
+        for f in range(3):
+            bt.track(frames[f & 1], sync=False)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for f in range(a.frames):
+            out = bt.track(frames[f & 1], sync=False)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        print(f"{B} sequences x {a.frames} frames of {H}x{W}: {B * a.frames / dt:.0f} frames/s end to end "
+              f"(host frames -> H2D -> crop -> graph -> state update), {dt / a.frames * 1e3:.2f} ms per step; "
+              f"H2D {B * H * W * 3 / 1e6:.0f} MB per step")
     dev = torch.from_numpy(frames).cuda()
     for f in range(3):       # caller-owned device frames take the eager path: warm it (a graph's first launch includes its upload)
         bt.track(dev[f & 1], sync=False)
