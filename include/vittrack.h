@@ -199,6 +199,12 @@ int vt_update_state_record(vt_model* m, const float* hann_boxes_dev, const float
 int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, double* states_dev, double factor, const float* mean3,
                   const float* std3, int32_t B, void* stream, float* crops_dev, double* resize_factor_dev, const vt_outputs* out,
                   int32_t margin, double* record);
+/* Open loop (on != 0): later vt_track_step calls -- and graphs captured from then on -- crop around states_dev, write the step's
+ * box and confidence to `record`, and leave states_dev as it is: every frame is searched around boxes the CALLER provides (the
+ * ground truth of an accuracy study; the held 30-90 px boxes of bench.py's tracker-step figures, which synthetic noise frames would
+ * otherwise drive to the clip limits within a few frames).  The reference's track() is the closed loop (lib/test/tracker/
+ * vit_dist.py:107-111 overwrites self.state), which stays the default; vt_update_state[_record] are not affected. */
+int vt_set_open_loop(vt_model* m, int32_t on);
 
 /* --- hipGraph: the whole track() device step captured once, replayed per frame -------------- */
 int vt_graph_capture(vt_model* m, const float* z_dev, const float* x_dev, int32_t B,

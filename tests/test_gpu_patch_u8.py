@@ -344,3 +344,64 @@ def test_track_step_with_another_mean_falls_back_to_the_fp32_crop(monkeypatch):
     for a, b in zip(*res):
         assert torch.equal(a, b)
     m.close()
+
+
+@pytest.mark.parametrize("geom,B", [(128, 3), (256, 2), (128, 200), (256, 130)])
+def test_open_loop_step_leaves_the_states_and_writes_the_same_record(geom, B):
+    """vt_set_open_loop: the step crops around the caller's boxes, the record (box + confidence) is the closed-loop step's bit for bit,
+    states_dev is not written; switching it off restores the closed loop.  Small- and large-batch head forms (both run the tail)."""
+    import torch
+    from vittracker_amd import native
+    m = _model(geom, B, seed=4)
+    H, W = 120, 160
+    frames = torch.from_numpy(np.random.RandomState(8).randint(0, 256, (2, B, H, W, 3)).astype(np.uint8)).cuda()
+    boxes = np.stack([[30 + (b % 40), 20 + (b % 30), 30 + (b % 7), 24 + (b % 5)] for b in range(B)]).astype(np.float64)
+    got = {}
+    for mode in ("closed", "open", "closed_again"):
+        m.set_open_loop(mode == "open")
+        states = torch.from_numpy(boxes).cuda()
+        z, rf = m.crop(frames[0], states, 2.0, geom // 2, MEAN, STD)
+        m.set_template(z)
+        x = torch.empty(B, 3, geom, geom, device="cuda")
+        out = native.Outputs(B, geom // 16, "cuda")
+        rec = torch.zeros(B, 5, dtype=torch.float64, device="cuda")
+        m.track_step(frames[1], states, 4.0, MEAN, STD, x, rf, out, record=rec)
+        torch.cuda.synchronize()
+        got[mode] = (rec.clone(), states.clone())
+    assert torch.equal(got["open"][0], got["closed"][0]) and torch.equal(got["closed_again"][0], got["closed"][0])
+    assert torch.equal(got["open"][1].cpu(), torch.from_numpy(boxes))                    # untouched
+    assert torch.equal(got["closed"][1], got["closed"][0][:, :4]) and torch.equal(got["closed_again"][1], got["closed"][1])
+    assert not torch.equal(got["closed"][1].cpu(), torch.from_numpy(boxes))
+    m.close()
+
+
+def test_hold_states_is_the_open_loop_in_eager_steps_and_chunk_graphs():
+    """BatchedVitTracker.hold_states(True): every step -- eager and inside a captured chunk graph -- searches around the held boxes (the
+    same frame gives the same record every time, the states never move); hold_states(False) resumes the closed loop."""
+    import torch
+    os.environ.setdefault("VITTRACK_PRJ_DIR", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vittracker_amd.batched import BatchedVitTracker
+    from vittracker_amd.parameter import vit_dist as P
+    p = P.parameters("vit_48_h32_g128")
+    p.allow_synthetic_weights = True
+    p.debug = 0
+    B, H, W = 6, 120, 160
+    rs = np.random.RandomState(3)
+    fr = torch.from_numpy(rs.randint(0, 256, (2, B, H, W, 3)).astype(np.uint8)).cuda()
+    boxes = np.stack([[30 + 5 * b, 20 + 4 * b, 30 + b, 24 + b] for b in range(B)]).astype(np.float64)
+    bt = BatchedVitTracker(p, B)
+    bt.initialize(fr[0], boxes)
+    bt.hold_states(True)
+    held = bt.states.clone()
+    chunk = fr[[1, 1, 0]].contiguous()
+    r1 = bt.track_chunk(chunk, sync=True)
+    r2 = bt.track_chunk(chunk, sync=True)
+    assert torch.equal(bt.states, held)
+    c1, c2 = np.asarray(r1["confidence"]), np.asarray(r2["confidence"])
+    assert np.array_equal(c1, c2) and np.array_equal(c1[0], c1[1]) and not np.array_equal(c1[0], c1[2])      # same frame, same boxes -> same result
+    e1 = bt.track(fr[1], sync=True)
+    assert torch.equal(bt.states, held)
+    assert np.array_equal(np.asarray(e1["confidence"].cpu()).ravel(), c1[0].ravel())
+    bt.hold_states(False)
+    bt.track_chunk(chunk, sync=True)
+    assert not torch.equal(bt.states, held)

@@ -24,8 +24,8 @@ def main():
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--size", type=int, nargs=2, default=[480, 640])
     ap.add_argument("--hold-boxes", action="store_true",
-                    help="reset every sequence's box to its initial one before each step (an 8 KB device copy per step inside the timed loops): on "
-                         "noise frames with random weights the boxes drift to the clip limits within a few frames -- 10 px wide at G128, the whole "
+                    help="open loop (vt_set_open_loop): every step searches around the sequences' INITIAL boxes, the result goes to the record only: on "
+                         "noise frames with random weights free-running boxes drift to the clip limits within a few frames -- 10 px wide at G128, the whole "
                          "frame at G256 -- and the crop then reads a 40 px or a 2200 px window; held boxes keep the 120-360 px windows of a tracker "
                          "that follows a target")
     ap.add_argument("--one-stream", action="store_true", help="stop before the two-shard phase (profiling: per-kernel times of ONE step in flight)")

@@ -67,7 +67,7 @@ class BatchedVitTracker:
         self.out = Outputs(batch, F, dev)
         self.graph = None            # captured at the first initialize(): the forward reads the cached template (z = None)
         self._chunk_graphs = {}      # (frame buffer address, n, H, W) -> whole-step graph of n frames (track_chunk)
-        self._held = None            # hold_states(): the boxes every step restarts from (benchmark aid)
+        self._held = None            # hold_states(): open loop, every step searches around the boxes it was switched on with
         self._chunk_buf = None
         self.frames = None
         self._fast_shape = None
@@ -156,12 +156,13 @@ class BatchedVitTracker:
         self.frame_id = 0
 
     def hold_states(self, on: bool = True):
-        """Benchmark aid: with on=True every later step starts from the boxes the sequences have NOW (one 32-byte-per-sequence device
-        copy in front of each step, inside the captured graphs too) instead of from the previous step's result.  On synthetic noise
-        frames with random weights a free-running tracker's boxes drift to the clip limits within a few frames, and the crop then
-        reads windows no real sequence has (tracking/track_batch_demo.py --hold-boxes)."""
-        self._held = self.states.clone() if on else None
-        self._chunk_graphs.clear()
+        """Benchmark / study aid: with on=True every later step searches around the boxes the sequences have NOW (open loop,
+        vt_set_open_loop: the step's boxes are in the records and the returned confidence, `states` stay) instead of around the previous
+        step's result.  On synthetic noise frames with random weights a free-running tracker's boxes drift to the clip limits within a
+        few frames, and the crop then reads windows no real sequence has (tracking/track_batch_demo.py --hold-boxes)."""
+        self._held = bool(on) or None
+        self.nat.set_open_loop(bool(on))
+        self._chunk_graphs.clear()      # the flag is an argument of the captured kernels
         self._fast = [None, None]
 
     def track_record(self, frames):
@@ -214,8 +215,6 @@ class BatchedVitTracker:
             return {"target_bbox": self.states, "confidence": self.out.conf}
         # a caller-owned device tensor (a new address every call would mean a new capture every call): eager launches, as ONE library
         # call (vt_track_step: crop -> network on the cached template with the state update on the head's decoding lane)
-        if self._held is not None:
-            self.states.copy_(self._held)
         self.nat.track_step(fr, self.states, self.params.search_factor, self.mean, self.std, self.x, self.rf, self.out, margin=10)
         if sync:
             return {"target_bbox": self.states.cpu(), "confidence": self.out.conf.cpu()}
@@ -247,8 +246,6 @@ class BatchedVitTracker:
         with torch.cuda.graph(g, stream=side):
             cs = torch.cuda.current_stream()
             for i in range(n):
-                if self._held is not None:
-                    self.states.copy_(self._held)
                 # vt_track_step = vt_crop -> vt_forward on the cached template -> vt_update_state_record in one library call
                 self.nat.track_step(buf[i], self.states, self.params.search_factor, self.mean, self.std, self.x, self.rf, self.out,
                                     record=rec[i], margin=10, stream=cs)

@@ -106,6 +106,7 @@ struct vt_model {
     int head_split = -1;             // F = 16: conv1 as a launch of its own over row strips (1 / 0 force, -1: by batch size)
     int tile_frames = 0;             // frames those workspaces are sized for
     int blocks_tile = -1;            // 1 / 0 force the tile-parallel form of the blocks / forbid it, -1 (default): by batch size
+    int open_loop = 0;               // vt_set_open_loop: vt_track_step leaves states_dev untouched (the step's box is in `record`)
     DevBuf zcache;                   // block-0 q / k / v^T images of the template tiles (vt_set_template)
     DevBuf vlscr;                    // G256 frame-form block kernel (A3): the low pieces of V^T, [B][depth][3][L / 32][64] x 16 B (vt_blocks.h VP2L)
     int tmpl_frames = 0;             // frames whose template rows (tokens + zcache) are cached
@@ -1818,6 +1819,12 @@ int vt_patch_u8_supported(const vt_model* m, int32_t B) {
     return stem_takes_u8(m, B) ? 1 : 0;
 }
 
+int vt_set_open_loop(vt_model* m, int32_t on) {
+    if (!m) return fail(VT_ERR_ARG, "null model");
+    m->open_loop = on ? 1 : 0;
+    return VT_OK;
+}
+
 int vt_crop_form(void) {
     bool bytes = false;
     if (crop_selftest(&bytes)) return -1;
@@ -1900,7 +1907,7 @@ int vt_track_step(vt_model* m, const uint8_t* frames, int32_t H, int32_t W, doub
     } else if ((rc = vt_crop(m, frames, H, W, states_dev, factor, m->cfg.search_size, mean3, std3, B, stream, crops_dev, resize_factor_dev))) return rc;
     if ((rc = run_stem(m, nullptr, crops_dev, B, st, m->tokens_c.p, 0, 1, u8))) return rc;
     if ((rc = run_blocks(m, m->tokens_c.p, B, -1, st, m->feat.p, nullptr, 2))) return rc;
-    const TrackTail tail{resize_factor_dev, states_dev, record, m->cfg.search_size, H, W, margin};
+    const TrackTail tail{resize_factor_dev, states_dev, record, m->cfg.search_size, H, W, margin, m->open_loop};
     return run_head(m, m->feat.p, B, st, out, 0, &tail);
 }
 

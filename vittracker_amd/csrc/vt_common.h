@@ -194,6 +194,7 @@ struct TrackTail {
     double* states;                // (B,4) [x,y,w,h], updated in place
     double* record;                // optional (B,5) [x,y,w,h,confidence]: device or device-mapped pinned host memory
     int search_size, H, W, margin;
+    int keep;                      // open loop (vt_set_open_loop): the new box goes to `record` only, `states` stay as they are
 };
 
 __device__ __forceinline__ void update_state_one(int b, const float (&hann_box)[4], float conf, const TrackTail& t) {
@@ -216,10 +217,12 @@ __device__ __forceinline__ void update_state_one(int b, const float (&hann_box)[
     by1 = fmin(fmax(0.0, by1), (double)(t.H - t.margin));
     by2 = fmin(fmax((double)t.margin, by2), (double)t.H);
     const double nw = fmax((double)t.margin, bx2 - bx1), nh = fmax((double)t.margin, by2 - by1);
-    t.states[4 * b + 0] = bx1;
-    t.states[4 * b + 1] = by1;
-    t.states[4 * b + 2] = nw;
-    t.states[4 * b + 3] = nh;
+    if (!t.keep) {
+        t.states[4 * b + 0] = bx1;
+        t.states[4 * b + 1] = by1;
+        t.states[4 * b + 2] = nw;
+        t.states[4 * b + 3] = nh;
+    }
     if (t.record != nullptr) {
         t.record[5 * b + 0] = bx1;
         t.record[5 * b + 1] = by1;

@@ -618,7 +618,7 @@ __global__ void update_state_kernel(const float* __restrict__ hann_boxes, const 
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float hb[4] = {hann_boxes[4 * b + 0], hann_boxes[4 * b + 1], hann_boxes[4 * b + 2], hann_boxes[4 * b + 3]};
-    const TrackTail t{resize_factor, states, record, search_size, H, W, margin};
+    const TrackTail t{resize_factor, states, record, search_size, H, W, margin, 0};
     update_state_one(b, hb, conf != nullptr ? conf[b] : 0.f, t);
 }
 

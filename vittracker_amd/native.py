@@ -25,7 +25,7 @@ SYMBOLS = [
     "vt_forward", "vt_stem", "vt_blocks", "vt_head", "vt_cal_bbox", "vt_graph_capture",
     "vt_graph_launch", "vt_graph_destroy", "vt_query", "vt_selftest_mfma", "vt_probe_clock", "vt_debug_stamps", "vt_crop", "vt_update_state",
     "vt_set_template", "vt_graph_capture_steps", "vt_update_state_record", "vt_track_step", "vt_set_form_batch",
-    "vt_crop_u8", "vt_set_normalization", "vt_forward_u8", "vt_stem_u8", "vt_patch_u8_supported", "vt_crop_form",
+    "vt_crop_u8", "vt_set_normalization", "vt_forward_u8", "vt_stem_u8", "vt_patch_u8_supported", "vt_crop_form", "vt_set_open_loop",
 ]
 
 
@@ -102,6 +102,7 @@ def lib(precision: str = "f32"):
     L.vt_stem_u8.argtypes = [vp, vp, i32, vp, vp]
     L.vt_patch_u8_supported.argtypes = [vp, i32]
     L.vt_crop_form.argtypes = []
+    L.vt_set_open_loop.argtypes = [vp, i32]
     if precision == "f32":
         _lib = L
     else:
@@ -439,6 +440,10 @@ class Model:
         m3 = (C.c_float * 3)(*[float(v) for v in mean])
         s3 = (C.c_float * 3)(*[float(v) for v in std])
         _check(self._L.vt_set_normalization(self._h, m3, s3), "vt_set_normalization", self._L)
+
+    def set_open_loop(self, on: bool = True):
+        """vt_set_open_loop: track_step (and graphs captured from now on) leave `states` untouched; the step's box is in `record`."""
+        _check(self._L.vt_set_open_loop(self._h, 1 if on else 0), "vt_set_open_loop", self._L)
 
     def patch_u8_supported(self, B: int) -> bool:
         return bool(self._L.vt_patch_u8_supported(self._h, int(B)))
