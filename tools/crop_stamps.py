@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase stamps of crop_band_kernel (uint8 form) from a -DVT_CROPF_DBG=16 build:
     VITTRACK_LIB=build_variants/cropstamp.so VT_CROP_BYTES=0 python tools/crop_stamps.py [T] [band]
-Every workgroup writes s_memtime at: start, geometry done, tables + barrier done, loads issued, loads arrived, end (over the first 48 bytes
+Every workgroup writes s_memtime at: start, geometry done, tables + barrier done, the first two items' loads issued, ... arrived, end (over the first 48 bytes
 of its band).  Printed relative to the launch's earliest start, as percentiles over the workgroups, in stamp ticks and us (the counter's
 rate is measured against a HIP-event-timed launch)."""
 import os
