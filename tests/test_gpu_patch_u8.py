@@ -103,6 +103,16 @@ for S in (64, 128, 256, 20, 30):
         want, want_rf = T._host_patch(frames[b], boxes[b], 2.0, S)
         assert np.array_equal(patch[b], want) and float(rf[b]) == want_rf, (S, boxes[b])
         assert np.array_equal(crop[b], P._host_crop(frames[b], boxes[b], 2.0, S)[0]) and float(rf2[b]) == want_rf, (S, boxes[b])
+# the batch's LAST frame is the one whose windows may end at the buffer's end (crop_band_kernel: the aligned form everywhere but in a band that
+# reads the frame's last row): every kind of box takes the last slot once
+for rot in (2, 21, 22):
+    bx, fr = boxes[rot:] + boxes[:rot], np.concatenate([frames[rot:], frames[:rot]])
+    for S in (128, 256):
+        patch, rf = m.crop_u8(torch.from_numpy(fr).cuda(), torch.tensor(bx, dtype=torch.float64).cuda(), 2.0, S)
+        patch = patch.cpu().numpy()
+        for b in (len(bx) - 2, len(bx) - 1):
+            want, want_rf = T._host_patch(fr[b], bx[b], 2.0, S)
+            assert np.array_equal(patch[b], want) and float(rf[b]) == want_rf, (rot, S, bx[b])
 print("FORM-OK")
 """ % (REPO, os.path.join(REPO, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
